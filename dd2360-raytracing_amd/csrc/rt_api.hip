@@ -1,0 +1,359 @@
+// rt_api.hip — the C-ABI of include/rt_amd.h: scene upload, octree flattening, kernel launches, PPM output.
+// Host code only (compiled by hipcc together with rt_kernels.hip into librt_amd.so).  No CPU render path exists
+// here: every compute entry point launches the gfx950 kernels or fails with the HIP error.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "rt_device.h"
+#include "../host/rt_scene.hpp"
+
+namespace rt {
+hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
+hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
+hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
+hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
+}
+
+using namespace rt;
+
+#define RT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Handles keep their host staging copy; device buffers are created by rt_world_upload / rt_octree_upload
+// (called implicitly by the first render/trace that uses the handle).
+struct rt_world {
+    int precision = RT_PRECISION_FP32;
+    int n = 0;
+    bool uploaded = false;
+    std::vector<float4> h_hot, h_geom, h_mat;
+    std::vector<int32_t> h_ids, h_kind;
+    DevScene dev{};
+    void* d_list_hot = nullptr; void* d_list_id = nullptr; void* d_geom = nullptr; void* d_mat = nullptr; void* d_kind = nullptr;
+};
+
+struct rt_octree {
+    int precision = RT_PRECISION_FP32;
+    Octree* host = nullptr;
+    bool uploaded = false;
+    std::vector<DevNode> h_nodes; std::vector<float4> h_ent_hot; std::vector<int32_t> h_ent_id;
+    DevTree dev{};
+    void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
+};
+
+template <class T> static int upload(const std::vector<T>& v, void** d) {
+    *d = nullptr;
+    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+    RT_TRY(hipMalloc(d, bytes));
+    if (!v.empty()) RT_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static bool valid_partition(rt_partition p) { return p.nparts >= 1 && p.part >= 0 && p.part < p.nparts; }
+static bool hittable(const rt_sphere& s) { return s.material != RT_MAT_NONE; }
+// radius*radius in real_t (sphere.h:21), as a float image
+static float radius_squared(const rt_sphere& s, int precision) {
+    if (precision == RT_PRECISION_FP16) { const half_t r(s.radius); return (r * r).f(); }
+    return s.radius * s.radius;
+}
+
+template <class R> static int create_world_impl(rt_sphere* list, int num_spheres, float sphere_radius, rt_camera* cam, int nx, int ny, rt_rand_state* st, int* num_created) {
+    world_t<R> W;
+    create_world<R>(W, num_spheres, sphere_radius, nx, ny, st);
+    W.d_world.serialise(list);
+    W.d_camera.serialise(*cam);
+    if (num_created) *num_created = W.created;
+    return 0;
+}
+
+template <class R> static void camera_impl(rt_camera* cam, const float* lf, const float* la, const float* up, float vfov, float aspect, float aperture, float focus) {
+    auto v = [](const float* p) { return vec3_t<R>(real_from<R>(p[0]), real_from<R>(p[1]), real_from<R>(p[2])); };
+    camera_t<R> c(v(lf), v(la), v(up), real_from<R>(vfov), real_from<R>(aspect), real_from<R>(aperture), real_from<R>(focus));
+    c.serialise(*cam);
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_check(int* device_count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (device_count) *device_count = (e == hipSuccess) ? n : 0;
+    if (e != hipSuccess) return (int)e;
+    if (n <= 0) return (int)hipErrorNoDevice;
+    return 0;
+}
+
+const char* rt_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case RT_EINVAL: return "invalid argument";
+        case RT_ENOMEM: return "out of host memory";
+        case RT_EIO: return "i/o error";
+        case RT_ENOTSUP: return "not supported";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scene definition
+int rt_rand_init(rt_rand_state* rand_state) {
+    if (!rand_state) return RT_EINVAL;
+    xorwow::init(*rand_state, 1984ull);
+    return 0;
+}
+
+int rt_create_world(rt_sphere* list, int num_spheres, float sphere_radius, rt_camera* cam, int nx, int ny, rt_rand_state* rand_state, int precision, int* num_created) {
+    if (!list || !cam || !rand_state || num_spheres < 5 || nx <= 0 || ny <= 0) return RT_EINVAL;   // NUM_SPHERES "just > 4" (main.cu:22)
+    try {
+        if (precision == RT_PRECISION_FP16) return create_world_impl<half_t>(list, num_spheres, sphere_radius, cam, nx, ny, rand_state, num_created);
+        if (precision == RT_PRECISION_FP32) return create_world_impl<float>(list, num_spheres, sphere_radius, cam, nx, ny, rand_state, num_created);
+    } catch (const std::bad_alloc&) { return RT_ENOMEM; }
+    return RT_EINVAL;
+}
+
+int rt_camera_init(rt_camera* cam, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov, float aspect, float aperture, float focus_dist, int precision) {
+    if (!cam || !lookfrom || !lookat || !vup) return RT_EINVAL;
+    if (precision == RT_PRECISION_FP16) camera_impl<half_t>(cam, lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist);
+    else if (precision == RT_PRECISION_FP32) camera_impl<float>(cam, lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist);
+    else return RT_EINVAL;
+    return 0;
+}
+
+int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam, int precision, rt_world** out) {
+    if (!list || !cam || !out || num_spheres <= 0) return RT_EINVAL;
+    if (precision != RT_PRECISION_FP32 && precision != RT_PRECISION_FP16) return RT_EINVAL;
+    *out = nullptr;
+    rt_world* W = new (std::nothrow) rt_world();
+    if (!W) return RT_ENOMEM;
+    W->precision = precision; W->n = num_spheres;
+    std::vector<float4>& hot = W->h_hot; std::vector<float4>& geom = W->h_geom; std::vector<float4>& mat = W->h_mat;
+    std::vector<int32_t>& ids = W->h_ids; std::vector<int32_t>& kind = W->h_kind;
+    geom.resize(num_spheres); mat.resize(num_spheres); kind.resize(num_spheres);
+    for (int i = 0; i < num_spheres; ++i) {
+        const rt_sphere& s = list[i];
+        geom[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius);
+        mat[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
+        kind[i] = s.material;
+        if (hittable(s)) { hot.push_back(make_float4(s.center[0], s.center[1], s.center[2], radius_squared(s, precision))); ids.push_back(i); }
+    }
+    W->dev.n = num_spheres; W->dev.n_list = (int)hot.size();
+    W->dev.ground_valid = hittable(list[0]) ? 1 : 0;
+    W->dev.cam = *cam;
+    *out = W;
+    return 0;
+}
+
+int rt_world_upload(rt_world* W) {
+    if (!W) return RT_EINVAL;
+    if (W->uploaded) return 0;
+    int rc;
+    if ((rc = upload(W->h_hot, &W->d_list_hot)) || (rc = upload(W->h_ids, &W->d_list_id)) || (rc = upload(W->h_geom, &W->d_geom)) ||
+        (rc = upload(W->h_mat, &W->d_mat)) || (rc = upload(W->h_kind, &W->d_kind))) return rc;
+    W->dev.list_hot = (const float4*)W->d_list_hot; W->dev.list_id = (const int32_t*)W->d_list_id;
+    W->dev.geom = (const float4*)W->d_geom; W->dev.mat = (const float4*)W->d_mat; W->dev.kind = (const int32_t*)W->d_kind;
+    W->uploaded = true;
+    return 0;
+}
+
+int rt_free_world(rt_world* W) {
+    if (!W) return 0;
+    int rc = 0;
+    void* bufs[5] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind};
+    for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
+    delete W;
+    return rc;
+}
+
+// pre-order flattening of the reference-layout tree (children in index order = traverseTree's visit order)
+static void flatten(const Octree& T, const rt_sphere* list, int precision, int node, std::vector<DevNode>& out, std::vector<float4>& ent_hot, std::vector<int32_t>& ent_id) {
+    const rt_octnode& n = T.nodes[node];
+    const size_t me = out.size();
+    DevNode d; memset(&d, 0, sizeof(d));
+    d.lo[0] = n.aabb[0]; d.lo[1] = n.aabb[1]; d.lo[2] = n.aabb[2]; d.hix = n.aabb[3]; d.hiy = n.aabb[4]; d.hiz = n.aabb[5];
+    d.ref_index = node; d.first = (int32_t)ent_id.size(); d.count = 0;
+    out.push_back(d);
+    if (n.level == 3) {
+        for (int i = 0; i < 8; ++i) {                            // buckets until the first empty child (:284-285)
+            const int leaf = n.children[i];
+            if (leaf == 0) break;
+            for (int j = 0; j < T.leaf_count[leaf]; ++j) {
+                const int si = T.leaf_indices[(size_t)leaf * T.spl + j];
+                if (si == 0 || !hittable(list[si])) continue;   // processHit skips index 0 (:255); ghosts are never hittable
+                const rt_sphere& s = list[si];
+                ent_hot.push_back(make_float4(s.center[0], s.center[1], s.center[2], radius_squared(s, precision)));
+                ent_id.push_back(si);
+            }
+        }
+        out[me].count = (int32_t)ent_id.size() - out[me].first;
+    } else {
+        for (int i = 0; i < 8; ++i) if (n.children[i] != 0) flatten(T, list, precision, n.children[i], out, ent_hot, ent_id);
+    }
+    out[me].skip = (int32_t)out.size();
+}
+
+int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_leaf, int precision, rt_octree** out) {
+    if (!list || !out || num_hitables <= 0 || spheres_per_leaf <= 0) return RT_EINVAL;
+    if (precision != RT_PRECISION_FP32 && precision != RT_PRECISION_FP16) return RT_EINVAL;
+    *out = nullptr;
+    rt_octree* O = new (std::nothrow) rt_octree();
+    if (!O) return RT_ENOMEM;
+    O->precision = precision;
+    try {
+        O->host = (precision == RT_PRECISION_FP16) ? buildOctree<half_t>(list, num_hitables, spheres_per_leaf)
+                                                   : buildOctree<float>(list, num_hitables, spheres_per_leaf);
+        flatten(*O->host, list, precision, 0, O->h_nodes, O->h_ent_hot, O->h_ent_id);
+        O->dev.n_nodes = (int)O->h_nodes.size(); O->dev.n_entries = (int)O->h_ent_id.size();
+    } catch (const std::bad_alloc&) { rt_free_octree(O); return RT_ENOMEM; }
+    *out = O;
+    return 0;
+}
+
+int rt_octree_upload(rt_octree* O) {
+    if (!O) return RT_EINVAL;
+    if (O->uploaded) return 0;
+    int rc;
+    if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_hot, &O->d_ent_hot)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
+    O->dev.nodes4 = (const float4*)O->d_nodes; O->dev.ent_hot = (const float4*)O->d_ent_hot; O->dev.ent_id = (const int32_t*)O->d_ent_id;
+    O->uploaded = true;
+    return 0;
+}
+
+// traversal copy (pre-order nodes with skip links, entry -> sphere index) for inspection
+int rt_octree_flat_info(const rt_octree* O, int* n_nodes, int* n_entries) {
+    if (!O) return RT_EINVAL;
+    if (n_nodes) *n_nodes = (int)O->h_nodes.size();
+    if (n_entries) *n_entries = (int)O->h_ent_id.size();
+    return 0;
+}
+
+int rt_free_octree(rt_octree* O) {
+    if (!O) return 0;
+    int rc = 0;
+    void* bufs[3] = {O->d_nodes, O->d_ent_hot, O->d_ent_id};
+    for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
+    delete O->host;      // the reference frees a new'ed Octree with free() (main.cu:473); here new/delete match
+    delete O;
+    return rc;
+}
+
+int rt_octree_info(const rt_octree* O, int* node_count, int* leaf_count, int* spheres_per_leaf, int* dropped_full, int* dropped_outside) {
+    if (!O || !O->host) return RT_EINVAL;
+    if (node_count) *node_count = O->host->nodeCount;
+    if (leaf_count) *leaf_count = O->host->leafCount;
+    if (spheres_per_leaf) *spheres_per_leaf = O->host->spl;
+    if (dropped_full) *dropped_full = O->host->dropped_full;
+    if (dropped_outside) *dropped_outside = O->host->dropped_outside;
+    return 0;
+}
+int rt_octree_nodes(const rt_octree* O, rt_octnode* out_nodes) {
+    if (!O || !O->host || !out_nodes) return RT_EINVAL;
+    memcpy(out_nodes, O->host->nodes.data(), sizeof(rt_octnode) * RT_OCTREE_MAX_NODES);
+    return 0;
+}
+int rt_octree_leaves(const rt_octree* O, int32_t* counts, int32_t* indices) {
+    if (!O || !O->host || !counts || !indices) return RT_EINVAL;
+    memcpy(counts, O->host->leaf_count.data(), sizeof(int32_t) * O->host->leafCount);
+    memcpy(indices, O->host->leaf_indices.data(), sizeof(int32_t) * (size_t)O->host->leafCount * O->host->spl);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the hot path
+int64_t rt_part_pixels(int max_x, int max_y, rt_partition part) {
+    if (max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
+    if (part.nparts == 1) return (int64_t)max_x * max_y;
+    const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
+    return (tiles - part.part + part.nparts - 1) / part.nparts * 64;
+}
+
+int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partition part, void* stream) {
+    if (max_x <= 0 || max_y <= 0 || !d_rand_state || !valid_partition(part)) return RT_EINVAL;
+    return (int)launch_render_init(d_rand_state, max_x, max_y, part.part, part.nparts, (hipStream_t)stream);
+}
+
+static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
+    if (!fb || !world || !d_rand_state || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
+    if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
+    if (world->precision != RT_PRECISION_FP32) return RT_ENOTSUP;
+    int rc = rt_world_upload(const_cast<rt_world*>(world));
+    if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
+    if (rc) return rc;
+    RenderArgs A;
+    A.fb = fb; A.rand_state = d_rand_state; A.max_x = max_x; A.max_y = max_y; A.ns = ns;
+    A.tiles_x = (max_x + 7) / 8; A.tiles_y = (max_y + 7) / 8;
+    A.part = part.part; A.nparts = part.nparts;
+    const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
+    A.n_local_tiles = (tiles - part.part + part.nparts - 1) / part.nparts;
+    A.scene = world->dev;
+    if (d_octree) A.tree = d_octree->dev; else memset(&A.tree, 0, sizeof(A.tree));
+    return (int)launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream);
+}
+
+int rt_render(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
+    return render_common(fb, max_x, max_y, ns, world, d_rand_state, d_octree, part, stream, 0);
+}
+
+int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
+    return render_common(fb, max_x, max_y, current_sample, world, d_rand_state, d_octree, part, stream, 1);
+}
+
+int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream) {
+    if (!fb_full || !fb_parts || max_x <= 0 || max_y <= 0 || nparts < 1) return RT_EINVAL;
+    if (precision != RT_PRECISION_FP32) return RT_ENOTSUP;
+    return (int)launch_assemble((float*)fb_full, (const float*)fb_parts, max_x, max_y, nparts, (hipStream_t)stream);
+}
+
+int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float* d_rays, int64_t n, rt_hit_record* d_out, void* stream) {
+    if (!world || !d_rays || !d_out || n < 0) return RT_EINVAL;
+    if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
+    if (world->precision != RT_PRECISION_FP32) return RT_ENOTSUP;
+    int rc = rt_world_upload(const_cast<rt_world*>(world));
+    if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
+    if (rc) return rc;
+    DevTree T; if (d_octree) T = d_octree->dev; else memset(&T, 0, sizeof(T));
+    return (int)launch_trace(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ output
+static float channel(const void* fb, size_t k, int precision) {
+    if (precision == RT_PRECISION_FP16) return half_bits_to_float(((const uint16_t*)fb)[k]);
+    return ((const float*)fb)[k];
+}
+
+int64_t rt_format_ppm(int nx, int ny, const void* fb, int precision, char* out, int64_t cap) {
+    if (nx <= 0 || ny <= 0 || !fb) return RT_EINVAL;
+    std::string s;
+    try {
+        s.reserve((size_t)nx * ny * 12 + 32);
+        s += "P3\n"; s += std::to_string(nx); s += ' '; s += std::to_string(ny); s += "\n255\n";
+        char line[48];
+        for (int j = ny - 1; j >= 0; j--) {
+            for (int i = 0; i < nx; i++) {
+                const size_t pixel_index = (size_t)j * nx + i;
+                const int ir = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 0, precision));
+                const int ig = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 1, precision));
+                const int ib = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 2, precision));
+                const int len = snprintf(line, sizeof(line), "%d %d %d\n", ir, ig, ib);
+                s.append(line, (size_t)len);
+            }
+        }
+    } catch (const std::bad_alloc&) { return RT_ENOMEM; }
+    if (out && (int64_t)s.size() <= cap) memcpy(out, s.data(), s.size());
+    return (int64_t)s.size();
+}
+
+int rt_write_ppm(const char* path, int nx, int ny, const void* fb, int precision) {
+    const int64_t need = rt_format_ppm(nx, ny, fb, precision, nullptr, 0);
+    if (need < 0) return (int)need;
+    std::string buf;
+    try { buf.resize((size_t)need); } catch (const std::bad_alloc&) { return RT_ENOMEM; }
+    rt_format_ppm(nx, ny, fb, precision, &buf[0], need);
+    FILE* f = path ? fopen(path, "wb") : stdout;
+    if (!f) return RT_EIO;
+    const size_t w = fwrite(buf.data(), 1, buf.size(), f);
+    if (path) fclose(f); else fflush(f);
+    return w == buf.size() ? 0 : RT_EIO;
+}
+
+} // extern "C"

@@ -1,0 +1,53 @@
+// rt_device.h — device-side data layout shared by the kernels (rt_kernels.hip) and the uploader (rt_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rt_amd.h"
+
+namespace rt {
+
+// One node of the traversal copy of the Octree, in depth-first pre-order (children in index order, the visit
+// order of traverseTree, acceleration_structure.h:276-304).  48 bytes = 3 x 16 B so a lane fetches it with
+// three ds_read_b128 from LDS.
+struct DevNode {
+    float lo[3];      // x_low, y_low, z_low
+    float hix;        // x_high
+    float hiy, hiz;   // y_high, z_high
+    int32_t skip;     // pre-order index of the next node when this one is culled (= end of its subtree)
+    int32_t first;    // level-3 node: first entry of its concatenated buckets in ent_hot / ent_id
+    int32_t count;    // level-3 node: number of entries (ghost entries removed); 0 for inner nodes
+    int32_t ref_index;// index of this node in the reference-layout nodes[] (diagnostics)
+    int32_t pad[2];
+};
+static_assert(sizeof(DevNode) == 48, "DevNode is 3 x float4");
+
+struct DevScene {
+    const float4* list_hot;   // [n_list] (cx, cy, cz, radius*radius) of the hittable spheres, list order
+    const int32_t* list_id;   // [n_list] index into the world list
+    const float4* geom;       // [n] (cx, cy, cz, radius)
+    const float4* mat;        // [n] (albedo r,g,b, param)
+    const int32_t* kind;      // [n] RT_MAT_*
+    int32_t n, n_list;
+    int32_t ground_valid;     // world list slot 0 is hittable (it is tested first by hitTree)
+    rt_camera cam;
+};
+
+struct DevTree {
+    const float4* nodes4;     // [n_nodes*3] DevNode as float4 triples
+    const float4* ent_hot;    // [n_entries] (cx, cy, cz, radius*radius) in traversal order
+    const int32_t* ent_id;    // [n_entries] index into the world list
+    int32_t n_nodes, n_entries;
+};
+
+struct RenderArgs {
+    void* fb;
+    rt_rand_state* rand_state;
+    int32_t max_x, max_y, ns;             // ns = current_sample for the progressive kernel
+    int32_t tiles_x, tiles_y;
+    int32_t part, nparts;
+    int64_t n_local_tiles;
+    DevScene scene;
+    DevTree tree;
+};
+
+} // namespace rt

@@ -1,0 +1,422 @@
+// rt_kernels.hip — hand-written HIP kernels of the render path for gfx950 (MI355X, CDNA4).
+//
+// Replaces the reference's device code: render_init / render / render_progressive (main.cu:84-142), color()
+// (main.cu:43-75), hitTree / traverseTree / intersect_ray_aabb / processHit (acceleration_structure.h:226-342),
+// hitable_list::hit (hitable_list.h:16-31), sphere::hit (sphere.h:17-46), the three material::scatter
+// (material.h:55-113) and camera::get_ray (camera.h:45-49).
+//
+// Shape:
+//   * one lane = one pixel (the per-pixel XORWOW stream is strictly serial), one wave64 = one 8x8 pixel tile;
+//   * the reference's `for sample { for bounce {..} }` nest is flattened into ONE loop per lane: a lane whose path
+//     ended starts its next sample at once instead of idling until the slowest path of the wave finishes;
+//   * no virtual calls, no device heap, no recursion: materials are a tag + 4 floats, the octree is a pre-order
+//     node array with skip links staged in LDS, bucket contents are pre-gathered (centre, r^2) float4 streams;
+//   * hitable_list path: the sphere index is wave-uniform, so sphere data comes through scalar loads (SGPR operands).
+//
+// Numeric contract: every floating-point operation below is one IEEE binary32 operation in the reference's
+// order; FMA contraction is off for the whole file (and on the command line); division and sqrt are the
+// correctly-rounded forms (hipcc default).  Values that are merely hoisted (a = d.d, radius^2) are bitwise the
+// values the reference recomputes.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "rt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace rt {
+
+#define RT_DEV static __device__ __forceinline__
+
+struct Rng { uint32_t d, v0, v1, v2, v3, v4; };
+
+// curand (XORWOW) + curand_uniform: x * 2^-32 + 2^-33, one rounding per operation
+RT_DEV float rng_uniform(Rng& s) {
+    const uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    const float x = (float)(s.d + s.v4);
+    const float m = x * 2.3283064e-10f;
+    return m + (2.3283064e-10f / 2.0f);
+}
+
+RT_DEV void rng_seed(Rng& s, unsigned long long seed) {       // curand_init(seed, 0, 0)
+    const uint32_t lo = (uint32_t)seed ^ 0xaad26b49u, hi = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * lo, t1 = 2591861531u * hi;
+    s.d = 6615241u + t1 + t0;
+    s.v0 = 123456789u + t0; s.v1 = 362436069u ^ t0; s.v2 = 521288629u + t1; s.v3 = 88675123u ^ t1; s.v4 = 5783321u + t0;
+}
+
+struct V3 { float x, y, z; };
+RT_DEV float dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }     // vec3.h:91, left to right
+
+struct RayF { V3 o, d; };
+
+// pow((1 - cosine), 5) of material.h:14 — contract: binary64 ((x*x)*(x*x))*x rounded once to binary32
+RT_DEV float pow5(float x) { const double v = (double)x; const double v2 = v * v; return (float)((v2 * v2) * v); }
+
+// ---------------------------------------------------------------------------------------------------- sphere::hit
+// One candidate test against (cx,cy,cz,r2).  closest is closest_so_far; on acceptance it is lowered and `best`
+// records which entry won.  Operation order of sphere.h:18-41 with a = d.d hoisted by the caller.
+RT_DEV void sphere_test(const RayF& r, float a, float cx, float cy, float cz, float r2, int id, float& closest, int& best) {
+    const float ocx = r.o.x - cx, ocy = r.o.y - cy, ocz = r.o.z - cz;
+    const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+    const float disc = b * b - a * c;
+    if (disc > 0.0f) {
+        const float sq = sqrtf(disc);
+        float t = (-b - sq) / a;
+        if (t < closest && t > 0.001f) { closest = t; best = id; }
+        else {
+            t = (-b + sq) / a;
+            if (t < closest && t > 0.001f) { closest = t; best = id; }
+        }
+    }
+}
+
+// intersect_ray_aabb — acceleration_structure.h:226-244 (comparisons kept literally: NaN/inf fall through as there)
+RT_DEV bool ray_box(const RayF& r, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+    float tmin = (lox - r.o.x) / r.d.x;
+    float tmax = (hix - r.o.x) / r.d.x;
+    if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (loy - r.o.y) / r.d.y;
+    float tymax = (hiy - r.o.y) / r.d.y;
+    if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (loz - r.o.z) / r.d.z;
+    float tzmax = (hiz - r.o.z) / r.d.z;
+    if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------- closest hit
+// hitable_list::hit over the hittable spheres in list order.  `k` is wave-uniform: scalar loads.
+RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, float& closest, int& best) {
+    const float4* __restrict__ hot = S.list_hot;
+    const int n = S.n_list;
+    for (int k = 0; k < n; ++k) {
+        const float4 s = hot[k];
+        sphere_test(r, a, s.x, s.y, s.z, s.w, k, closest, best);
+    }
+    if (best >= 0) best = S.list_id[best];
+}
+
+// hitTree: ground sphere first, then the tree in the reference's depth-first order (pre-order array + skip links).
+// While-while form: every lane first advances to its next non-empty level-3 node that passes the slab test,
+// then all lanes scan their node's entries.
+RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
+    if (S.ground_valid) {
+        const float4 g = S.list_hot[0];
+        int gb = -1;
+        sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
+        if (gb == 0) best = 0;
+    }
+    int e_best = -1;
+    int node = live ? 0 : T.n_nodes;
+    const int n_nodes = T.n_nodes;
+    while (true) {
+        int e = 0, e_end = 0;
+        while (node < n_nodes) {
+            const float4 n0 = s_nodes[node * 3 + 0];
+            const float4 n1 = s_nodes[node * 3 + 1];
+            const float4 n2 = s_nodes[node * 3 + 2];
+            const int skip = __float_as_int(n1.z);
+            if (ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y)) {
+                const int cnt = __float_as_int(n2.x);
+                node = node + 1;
+                if (cnt > 0) { e = __float_as_int(n1.w); e_end = e + cnt; break; }
+            } else {
+                node = skip;
+            }
+        }
+        if (e >= e_end) break;          // no node left for this lane (it waits at the loop exit for the rest of the wave)
+        for (; e < e_end; ++e) {
+            const float4 s = T.ent_hot[e];
+            sphere_test(r, a, s.x, s.y, s.z, s.w, e, closest, e_best);
+        }
+    }
+    if (e_best >= 0) best = T.ent_id[e_best];
+}
+
+// ---------------------------------------------------------------------------------------------------- sampling
+RT_DEV V3 random_in_unit_sphere(Rng& s) {               // material.h:35-41
+    V3 p;
+    do {
+        const float x = rng_uniform(s); const float y = rng_uniform(s); const float z = rng_uniform(s);
+        p.x = 2.0f * x - 1.0f; p.y = 2.0f * y - 1.0f; p.z = 2.0f * z - 1.0f;
+    } while (p.x * p.x + p.y * p.y + p.z * p.z >= 1.0f);
+    return p;
+}
+
+// camera::get_ray + the two pixel-jitter draws (main.cu:104-106, camera.h:12-18, :45-49)
+RT_DEV RayF primary_ray(const rt_camera& c, int i, int j, int max_x, int max_y, Rng& s) {
+    const float u = ((float)i + rng_uniform(s)) / (float)max_x;
+    const float v = ((float)j + rng_uniform(s)) / (float)max_y;
+    float px, py;
+    do {
+        const float x = rng_uniform(s); const float y = rng_uniform(s);
+        px = 2.0f * x - 1.0f; py = 2.0f * y - 1.0f;
+    } while (px * px + py * py + 0.0f >= 1.0f);
+    const float rdx = c.lens_radius * px, rdy = c.lens_radius * py;
+    RayF r;
+    const float ox = rdx * c.u[0] + rdy * c.v[0], oy = rdx * c.u[1] + rdy * c.v[1], oz = rdx * c.u[2] + rdy * c.v[2];
+    r.o.x = c.origin[0] + ox; r.o.y = c.origin[1] + oy; r.o.z = c.origin[2] + oz;
+    r.d.x = (((c.lower_left_corner[0] + u * c.horizontal[0]) + v * c.vertical[0]) - c.origin[0]) - ox;
+    r.d.y = (((c.lower_left_corner[1] + u * c.horizontal[1]) + v * c.vertical[1]) - c.origin[1]) - oy;
+    r.d.z = (((c.lower_left_corner[2] + u * c.horizontal[2]) + v * c.vertical[2]) - c.origin[2]) - oz;
+    return r;
+}
+
+// material::scatter for the sphere that was hit.  Returns false when the path is absorbed (metal, material.h:72).
+RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rng& s) {
+    const float4 g = S.geom[sphere];
+    const float4 m = S.mat[sphere];
+    const int kind = S.kind[sphere];
+    V3 p, n;
+    p.x = r.o.x + t * r.d.x; p.y = r.o.y + t * r.d.y; p.z = r.o.z + t * r.d.z;            // ray.h:13
+    n.x = (p.x - g.x) / g.w; n.y = (p.y - g.y) / g.w; n.z = (p.z - g.z) / g.w;            // sphere.h:29
+    if (kind == RT_MAT_LAMBERTIAN) {                                                          // material.h:55-60
+        const V3 q = random_in_unit_sphere(s);
+        const float tx = (p.x + n.x) + q.x, ty = (p.y + n.y) + q.y, tz = (p.z + n.z) + q.z;
+        r.d.x = tx - p.x; r.d.y = ty - p.y; r.d.z = tz - p.z;
+        r.o = p;
+        att.x *= m.x; att.y *= m.y; att.z *= m.z;
+        return true;
+    }
+    if (kind == RT_MAT_METAL) {                                                               // material.h:68-73
+        const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
+        V3 ud; ud.x = r.d.x / len; ud.y = r.d.y / len; ud.z = r.d.z / len;
+        const float k = 2.0f * dot3(ud, n);
+        const float rx = ud.x - k * n.x, ry = ud.y - k * n.y, rz = ud.z - k * n.z;
+        const V3 q = random_in_unit_sphere(s);
+        r.d.x = rx + m.w * q.x; r.d.y = ry + m.w * q.y; r.d.z = rz + m.w * q.z;
+        r.o = p;
+        att.x *= m.x; att.y *= m.y; att.z *= m.z;
+        return dot3(r.d, n) > 0.0f;
+    }
+    // dielectric — material.h:81-113 (attenuation (1,1,1): the multiply is exact and omitted)
+    const float ri = m.w;
+    const float dn = dot3(r.d, n);
+    const float k = 2.0f * dn;
+    const float rx = r.d.x - k * n.x, ry = r.d.y - k * n.y, rz = r.d.z - k * n.z;            // reflect(dir, normal), dir not normalised
+    const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
+    V3 on; float ni, cosine;
+    if (dn > 0.0f) {
+        on.x = -n.x; on.y = -n.y; on.z = -n.z; ni = ri;
+        cosine = dn / len;
+        cosine = sqrtf(1.0f - ri * ri * (1.0f - cosine * cosine));
+    } else {
+        on = n; ni = 1.0f / ri;
+        cosine = -dn / len;
+    }
+    V3 uv; uv.x = r.d.x / len; uv.y = r.d.y / len; uv.z = r.d.z / len;                        // refract(), material.h:17-31
+    const float dt = dot3(uv, on);
+    const float disc = 1.0f - ni * ni * (1.0f - dt * dt);
+    float fx = 0.0f, fy = 0.0f, fz = 0.0f, reflect_prob;
+    if (disc > 0.0f) {
+        const float sq = sqrtf(disc);
+        fx = ni * (uv.x - dt * on.x) - sq * on.x;
+        fy = ni * (uv.y - dt * on.y) - sq * on.y;
+        fz = ni * (uv.z - dt * on.z) - sq * on.z;
+        float r0 = (1.0f - ri) / (1.0f + ri);                                                // schlick(), material.h:11-15
+        r0 = r0 * r0;
+        reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
+    } else {
+        reflect_prob = 1.0f;
+    }
+    r.o = p;
+    if (rng_uniform(s) < reflect_prob) { r.d.x = rx; r.d.y = ry; r.d.z = rz; }
+    else { r.d.x = fx; r.d.y = fy; r.d.z = fz; }
+    return true;
+}
+
+// background gradient of color() — main.cu:67-72
+RT_DEV V3 sky(const RayF& r, const V3& att) {
+    const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
+    const float uy = r.d.y / len;
+    const float t = 0.5f * (uy + 1.0f);
+    const float omt = 1.0f - t;
+    V3 c;
+    c.x = att.x * (omt + t * 0.5f);
+    c.y = att.y * (omt + t * 0.7f);
+    c.z = att.z * (omt + t * 1.0f);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------- kernels
+__global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, int max_x, int max_y, int tiles_x, int part, int nparts, long long n_local_tiles) {
+    const int lane = threadIdx.x & 63;
+    const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (local_tile >= n_local_tiles) return;
+    const long long tile = part + local_tile * nparts;
+    const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+    const bool inside = (i < max_x) && (j < max_y);
+    if (nparts == 1 && !inside) return;
+    const long long idx = (nparts == 1) ? (long long)j * max_x + i : local_tile * 64 + lane;
+    const int pixel_index = j * max_x + i;
+    Rng s; rng_seed(s, 1984ull + (unsigned long long)(long long)pixel_index);
+    rt_rand_state out;
+    out.d = s.d; out.v[0] = s.v0; out.v[1] = s.v1; out.v[2] = s.v2; out.v[3] = s.v3; out.v[4] = s.v4;
+    out.boxmuller_flag = 0; out.boxmuller_flag_double = 0; out.boxmuller_extra = 0.f; out.pad_ = 0; out.boxmuller_extra_double = 0.0;
+    rand_state[idx] = out;
+}
+
+// MODE 0: render (ns samples, /ns, sqrt).  MODE 1: render_progressive (one sample, accumulate).
+template <bool TREE, int MODE>
+__global__ __launch_bounds__(256) void k_render(RenderArgs A) {
+    extern __shared__ float4 s_nodes[];
+    if (TREE) {
+        const int n4 = A.tree.n_nodes * 3;
+        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (local_tile >= A.n_local_tiles) return;
+    const long long tile = A.part + local_tile * A.nparts;
+    const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+    const bool inside = (i < A.max_x) && (j < A.max_y);
+    const long long idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + lane;
+
+    Rng s = {0, 0, 0, 0, 0, 0};
+    if (inside) {
+        const rt_rand_state* st = A.rand_state + idx;
+        s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
+    }
+    const int ns = (MODE == 0) ? A.ns : 1;
+    V3 col = {0.0f, 0.0f, 0.0f};
+    V3 att = {1.0f, 1.0f, 1.0f};
+    RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
+    int sample = 0, depth = 0;
+    bool live = inside && ns > 0;
+    if (live) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+
+    while (__ballot(live) != 0ull) {
+        const float a = dot3(r.d, r.d);
+        float closest = FLT_MAX; int best = -1;
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best);
+        else closest_list(A.scene, r, a, closest, best);
+        if (live) {
+            bool done;                                     // this sample's path has ended
+            if (best >= 0) {
+                const bool cont = scatter(A.scene, best, closest, r, att, s);
+                ++depth;
+                done = !cont || depth >= 50;               // absorbed, or 50 bounces used up: contributes (0,0,0)
+            } else {
+                const V3 c = sky(r, att);
+                col.x += c.x; col.y += c.y; col.z += c.z;
+                done = true;
+            }
+            if (done) {
+                ++sample; depth = 0; att = {1.0f, 1.0f, 1.0f};
+                if (sample < ns) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+                else live = false;
+            }
+        }
+    }
+
+    if (!inside) return;
+    rt_rand_state* st = A.rand_state + idx;
+    st->d = s.d; st->v[0] = s.v0; st->v[1] = s.v1; st->v[2] = s.v2; st->v[3] = s.v3; st->v[4] = s.v4;
+    float* fb = (float*)A.fb + idx * 3;
+    if (MODE == 0) {
+        const float k = (float)(1.0 / (double)(float)A.ns);          // vec3::operator/=(real_t): 1.0/t in double (vec3.h:137)
+        col.x *= k; col.y *= k; col.z *= k;
+        fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
+    } else {
+        if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
+        else { fb[0] += col.x; fb[1] += col.y; fb[2] += col.z; }
+    }
+}
+
+// hitTree / hitable_list::hit for a batch of rays (one lane per ray)
+template <bool TREE>
+__global__ __launch_bounds__(256) void k_trace(DevScene S, DevTree T, const float* rays, long long n, rt_hit_record* out) {
+    extern __shared__ float4 s_nodes[];
+    if (TREE) {
+        const int n4 = T.n_nodes * 3;
+        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = T.nodes4[t];
+        __syncthreads();
+    }
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = gid < n;
+    RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
+    if (live) { const float* p = rays + gid * 6; r.o = {p[0], p[1], p[2]}; r.d = {p[3], p[4], p[5]}; }
+    const float a = dot3(r.d, r.d);
+    float closest = FLT_MAX; int best = -1;
+    if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best);
+    else closest_list(S, r, a, closest, best);
+    if (!live) return;
+    rt_hit_record h;
+    h.sphere = best; h.t = 0.f; h.p[0] = h.p[1] = h.p[2] = 0.f; h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
+    if (best >= 0) {
+        const float4 g = S.geom[best];
+        h.t = closest;
+        h.p[0] = r.o.x + closest * r.d.x; h.p[1] = r.o.y + closest * r.d.y; h.p[2] = r.o.z + closest * r.d.z;
+        h.normal[0] = (h.p[0] - g.x) / g.w; h.normal[1] = (h.p[1] - g.y) / g.w; h.normal[2] = (h.p[2] - g.z) / g.w;
+    }
+    out[gid] = h;
+}
+
+// gather of tile-major part buffers into the row-major frame (after the multi-GPU all-gather)
+__global__ __launch_bounds__(256) void k_assemble(float* full, const float* parts, int max_x, int max_y, int tiles_x, int nparts, long long part_stride_px, long long n_tiles) {
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+    if (i >= max_x || j >= max_y) return;
+    const long long src = (tile % nparts) * part_stride_px + (tile / nparts) * 64 + lane;
+    const long long dst = (long long)j * max_x + i;
+    full[dst * 3 + 0] = parts[src * 3 + 0]; full[dst * 3 + 1] = parts[src * 3 + 1]; full[dst * 3 + 2] = parts[src * 3 + 2];
+}
+
+// ---------------------------------------------------------------------------------------------------- launchers
+hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st) {
+    const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
+    const long long tiles = (long long)tiles_x * tiles_y;
+    const long long local = (tiles - part + nparts - 1) / nparts;
+    if (local <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((local + 3) / 4);
+    hipLaunchKernelGGL(k_render_init, dim3(blocks), dim3(256), 0, st, rs, max_x, max_y, tiles_x, part, nparts, local);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
+    if (A.n_local_tiles <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((A.n_local_tiles + 3) / 4);
+    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
+    if (tree) {
+        if (mode == 0) hipLaunchKernelGGL((k_render<true, 0>), dim3(blocks), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((k_render<true, 1>), dim3(blocks), dim3(256), lds, st, A);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((k_render<false, 0>), dim3(blocks), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((k_render<false, 1>), dim3(blocks), dim3(256), lds, st, A);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) : 0;
+    if (tree) hipLaunchKernelGGL((k_trace<true>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
+    else hipLaunchKernelGGL((k_trace<false>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st) {
+    const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
+    const long long tiles = (long long)tiles_x * tiles_y;
+    const long long per_part = (tiles + nparts - 1) / nparts * 64;
+    const unsigned blocks = (unsigned)((tiles + 3) / 4);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, st, full, parts, max_x, max_y, tiles_x, nparts, per_part, tiles);
+    return hipGetLastError();
+}
+
+} // namespace rt

@@ -1,0 +1,259 @@
+"""ctypes binding of librt_amd.so (include/rt_amd.h) — the thin Python layer used by tests/, bench.py and
+__graft_entry__.py.  The product is the C-ABI library and the C++ host program (host/main.cpp); this module only
+marshals arguments.  Device memory, streams and process groups come from PyTorch (plumbing only).
+
+There is no fallback of any kind: if librt_amd.so cannot be loaded, or a call returns non-zero, RtError is raised.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+FP32, FP16 = 0, 1
+MAT_NONE, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = -1, 0, 1, 2
+OCTREE_MAX_NODES = 585
+
+# PODs of include/rt_amd.h
+rand_state_dtype = np.dtype([("d", "<u4"), ("v", "<u4", 5), ("boxmuller_flag", "<i4"), ("boxmuller_flag_double", "<i4"),
+                             ("boxmuller_extra", "<f4"), ("pad_", "<u4"), ("boxmuller_extra_double", "<f8")])
+sphere_dtype = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("material", "<i4"), ("albedo", "<f4", 3), ("param", "<f4")])
+camera_dtype = np.dtype([("origin", "<f4", 3), ("lower_left_corner", "<f4", 3), ("horizontal", "<f4", 3), ("vertical", "<f4", 3),
+                         ("u", "<f4", 3), ("v", "<f4", 3), ("w", "<f4", 3), ("lens_radius", "<f4")])
+octnode_dtype = np.dtype([("level", "<i4"), ("aabb", "<f4", 6), ("children", "<i4", 8)])
+hit_record_dtype = np.dtype([("t", "<f4"), ("p", "<f4", 3), ("normal", "<f4", 3), ("sphere", "<i4")])
+assert rand_state_dtype.itemsize == 48 and sphere_dtype.itemsize == 36 and camera_dtype.itemsize == 88
+assert octnode_dtype.itemsize == 60 and hit_record_dtype.itemsize == 32
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Partition(C.Structure):
+    _fields_ = [("part", C.c_int32), ("nparts", C.c_int32)]
+
+
+WHOLE = Partition(0, 1)
+
+# every symbol include/rt_amd.h declares: (restype, argtypes)
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "rt_abi_version": (_i, []),
+    "rt_device_check": (_i, [_vp]),
+    "rt_error_string": (C.c_char_p, [_i]),
+    "rt_rand_init": (_i, [_vp]),
+    "rt_create_world": (_i, [_vp, _i, _f, _vp, _i, _i, _vp, _i, _vp]),
+    "rt_camera_init": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _f, _i]),
+    "rt_world_create": (_i, [_vp, _i, _vp, _i, _vp]),
+    "rt_world_upload": (_i, [_vp]),
+    "rt_free_world": (_i, [_vp]),
+    "rt_build_octree": (_i, [_vp, _i, _i, _i, _vp]),
+    "rt_octree_upload": (_i, [_vp]),
+    "rt_free_octree": (_i, [_vp]),
+    "rt_octree_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rt_octree_flat_info": (_i, [_vp, _vp, _vp]),
+    "rt_octree_nodes": (_i, [_vp, _vp]),
+    "rt_octree_leaves": (_i, [_vp, _vp, _vp]),
+    "rt_part_pixels": (_i64, [_i, _i, Partition]),
+    "rt_render_init": (_i, [_i, _i, _vp, Partition, _vp]),
+    "rt_render": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
+    "rt_render_progressive": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
+    "rt_assemble": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rt_trace_rays": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "rt_write_ppm": (_i, [C.c_char_p, _i, _i, _vp, _i]),
+    "rt_format_ppm": (_i64, [_i, _i, _vp, _i, _vp, _i64]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load librt_amd.so.  Raises RtError when it is missing or does not export the whole ABI (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError("librt_amd.so is not built (%s): run __graft_entry__.build() / make -C dd2360-raytracing_amd" % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RtError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                raise RtError("librt_amd.so does not export %s" % name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().rt_error_string(int(rc))
+        raise RtError("%s failed: %d (%s)" % (what, rc, msg.decode() if msg else "?"))
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dev(t):
+    """device pointer of a torch tensor (or a raw int)"""
+    return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_check():
+    n = C.c_int(0)
+    rc = lib().rt_device_check(C.byref(n))
+    return rc, n.value
+
+
+def part_pixels(max_x, max_y, part=WHOLE):
+    n = lib().rt_part_pixels(max_x, max_y, part)
+    if n < 0:
+        raise RtError("rt_part_pixels: invalid argument")
+    return n
+
+
+class World:
+    """rand_init + create_world of main.cu:388-401 (host side), and the device scene they feed."""
+
+    def __init__(self, num_spheres, nx, ny, sphere_radius=0.1, precision=FP32, spheres=None, camera=None):
+        L = lib()
+        self.num_spheres, self.nx, self.ny, self.precision = num_spheres, nx, ny, precision
+        self.rand_state = np.zeros(1, rand_state_dtype)
+        if spheres is None:
+            self.spheres = np.zeros(num_spheres, sphere_dtype)
+            self.camera = np.zeros(1, camera_dtype)
+            created = C.c_int(0)
+            check(L.rt_rand_init(_np(self.rand_state)), "rt_rand_init")
+            check(L.rt_create_world(_np(self.spheres), num_spheres, sphere_radius, _np(self.camera), nx, ny, _np(self.rand_state),
+                                    precision, C.byref(created)), "rt_create_world")
+            self.created = created.value
+        else:
+            self.spheres = np.ascontiguousarray(spheres, sphere_dtype)
+            self.camera = np.ascontiguousarray(camera, camera_dtype).reshape(1)
+            self.created = int((self.spheres["material"] != MAT_NONE).sum())
+        h = C.c_void_p()
+        check(L.rt_world_create(_np(self.spheres), num_spheres, _np(self.camera), precision, C.byref(h)), "rt_world_create")
+        self.h = h
+
+    def upload(self):
+        check(lib().rt_world_upload(self.h), "rt_world_upload")
+        return self
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_free_world(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Octree:
+    """buildOctree (acceleration_structure.h:195) + upload (main.cu:413-417)."""
+
+    def __init__(self, world, spheres_per_leaf=30):
+        L = lib()
+        self.world, self.spl = world, spheres_per_leaf
+        h = C.c_void_p()
+        check(L.rt_build_octree(_np(world.spheres), world.num_spheres, spheres_per_leaf, world.precision, C.byref(h)), "rt_build_octree")
+        self.h = h
+
+    def upload(self):
+        check(lib().rt_octree_upload(self.h), "rt_octree_upload")
+        return self
+
+    def info(self):
+        v = [C.c_int(0) for _ in range(5)]
+        check(lib().rt_octree_info(self.h, *[C.byref(x) for x in v]), "rt_octree_info")
+        fn, fe = C.c_int(0), C.c_int(0)
+        check(lib().rt_octree_flat_info(self.h, C.byref(fn), C.byref(fe)), "rt_octree_flat_info")
+        keys = ["node_count", "leaf_count", "spl", "dropped_full", "dropped_outside"]
+        d = dict(zip(keys, [x.value for x in v]))
+        d.update(flat_nodes=fn.value, flat_entries=fe.value)
+        return d
+
+    def nodes(self):
+        out = np.zeros(OCTREE_MAX_NODES, octnode_dtype)
+        check(lib().rt_octree_nodes(self.h, _np(out)), "rt_octree_nodes")
+        return out
+
+    def leaves(self):
+        lc = self.info()["leaf_count"]
+        counts = np.zeros(lc, np.int32)
+        idx = np.zeros((lc, self.spl), np.int32)
+        check(lib().rt_octree_leaves(self.h, _np(counts), _np(idx)), "rt_octree_leaves")
+        return counts, idx
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_free_octree(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def camera_init(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist, precision=FP32):
+    cam = np.zeros(1, camera_dtype)
+    a = [np.asarray(x, np.float32) for x in (lookfrom, lookat, vup)]
+    check(lib().rt_camera_init(_np(cam), _np(a[0]), _np(a[1]), _np(a[2]), vfov, aspect, aperture, focus_dist, precision), "rt_camera_init")
+    return cam
+
+
+# ---- device-side calls: buffers are torch CUDA tensors -------------------------------------------------------------
+def alloc_rand_state(max_x, max_y, part=WHOLE, device="cuda"):
+    import torch
+    return torch.zeros(part_pixels(max_x, max_y, part) * 48, dtype=torch.uint8, device=device)
+
+
+def alloc_fb(max_x, max_y, part=WHOLE, precision=FP32, device="cuda"):
+    import torch
+    return torch.zeros(part_pixels(max_x, max_y, part) * 3, dtype=torch.float32 if precision == FP32 else torch.float16, device=device)
+
+
+def render_init(max_x, max_y, d_rand_state, part=WHOLE):
+    check(lib().rt_render_init(max_x, max_y, _dev(d_rand_state), part, _stream()), "rt_render_init")
+
+
+def render(fb, max_x, max_y, ns, world, d_rand_state, octree=None, part=WHOLE):
+    check(lib().rt_render(_dev(fb), max_x, max_y, ns, world.h, _dev(d_rand_state), octree.h if octree is not None else None, part, _stream()),
+          "rt_render")
+
+
+def render_progressive(fb, max_x, max_y, current_sample, world, d_rand_state, octree=None, part=WHOLE):
+    check(lib().rt_render_progressive(_dev(fb), max_x, max_y, current_sample, world.h, _dev(d_rand_state),
+                                      octree.h if octree is not None else None, part, _stream()), "rt_render_progressive")
+
+
+def assemble(fb_full, fb_parts, max_x, max_y, nparts, precision=FP32):
+    check(lib().rt_assemble(_dev(fb_full), _dev(fb_parts), max_x, max_y, nparts, precision, _stream()), "rt_assemble")
+
+
+def trace_rays(world, octree, d_rays, n, d_out):
+    check(lib().rt_trace_rays(world.h, octree.h if octree is not None else None, _dev(d_rays), n, _dev(d_out), _stream()), "rt_trace_rays")
+
+
+def format_ppm(fb_host, nx, ny, precision=FP32):
+    fb_host = np.ascontiguousarray(fb_host)
+    n = lib().rt_format_ppm(nx, ny, _np(fb_host), precision, None, 0)
+    if n < 0:
+        raise RtError("rt_format_ppm failed: %d" % n)
+    buf = C.create_string_buffer(n)
+    lib().rt_format_ppm(nx, ny, _np(fb_host), precision, buf, n)
+    return buf.raw[:n]

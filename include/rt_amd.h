@@ -1,0 +1,172 @@
+/* rt_amd.h — C-ABI of the MI355X-native render path (librt_amd.so).
+ *
+ * Drop-in boundary for the render path of MuellerNico/DD2360-RayTracing.  The reference has no FFI layer: its
+ * boundary is the kernel-launch surface of main.cu plus two host functions.  Every entry point
+ * below names the reference interface it replaces (file:line under the reference tree).  POD only, plain
+ * pointers and sizes, `int` return (0 = ok, otherwise the hipError_t value, or a negative RT_E* code for argument
+ * errors); no exceptions cross the boundary; the caller owns every buffer it passes in; opaque handles are
+ * created/destroyed by the matching rt_* calls.  All device work is enqueued on the caller-supplied stream
+ * (a hipStream_t passed as void*, NULL = default stream) and is asynchronous unless stated otherwise.
+ * Thread-compatible, not thread-safe per handle.
+ *
+ * There is NO CPU fallback: every compute entry point fails (hipError) when no gfx950 device / code object is
+ * available.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* argument errors (negative so they never collide with hipError_t) */
+#define RT_EINVAL (-1)
+#define RT_ENOMEM (-2)
+#define RT_EIO (-3)
+#define RT_ENOTSUP (-4)
+
+/* real_t selection — precision_types.h:8 (USE_FP16) */
+#define RT_PRECISION_FP32 0
+#define RT_PRECISION_FP16 1
+
+/* material tags — lambertian / metal / dielectric of material.h:52,62,76; NONE marks a never-initialised
+ * ("ghost") slot of the world list (main.cu:160-190 fills only 4+k*k of NUM_SPHERES slots): never hittable. */
+#define RT_MAT_NONE (-1)
+#define RT_MAT_LAMBERTIAN 0
+#define RT_MAT_METAL 1
+#define RT_MAT_DIELECTRIC 2
+
+/* curandState (48 bytes) — the per-pixel RNG state buffer of main.cu:383 keeps this layout. */
+typedef struct rt_rand_state {
+    uint32_t d, v[5];
+    int32_t boxmuller_flag, boxmuller_flag_double;
+    float boxmuller_extra;
+    uint32_t pad_;
+    double boxmuller_extra_double;
+} rt_rand_state;
+
+/* sphere (sphere.h:7-15) together with the material its mat_ptr points to (material.h:52-116).
+ * In FP16 mode every float holds the exact image of the binary16 value. */
+typedef struct rt_sphere {
+    float center[3];
+    float radius;
+    int32_t material;   /* RT_MAT_* */
+    float albedo[3];    /* lambertian / metal */
+    float param;        /* metal: fuzz (already clamped to <=1, material.h:66); dielectric: ref_idx */
+} rt_sphere;
+
+/* camera (camera.h:51-56), same field order. */
+typedef struct rt_camera {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius;
+} rt_camera;
+
+/* OctNode (acceleration_structure.h:35-39), reference layout, for inspection of the built tree. */
+typedef struct rt_octnode {
+    int32_t level;
+    float aabb[6];      /* x_low,y_low,z_low,x_high,y_high,z_high */
+    int32_t children[8];
+} rt_octnode;
+
+#define RT_OCTREE_MAX_NODES 585 /* NUMBER_NODES, acceleration_structure.h:13 */
+
+/* hit_record (hitable.h:9-15); mat_ptr becomes the index of the sphere that was hit (-1 = miss). */
+typedef struct rt_hit_record {
+    float t;
+    float p[3];
+    float normal[3];
+    int32_t sphere;
+} rt_hit_record;
+
+typedef struct rt_world rt_world;   /* device-resident scene: what d_list / d_world / d_camera reach (main.cu:393-398) */
+typedef struct rt_octree rt_octree; /* Octree (acceleration_structure.h:57-62): host reference layout + device traversal copy */
+
+/* Which pixel tiles of the frame this call covers.  The frame is cut into 8x8-pixel tiles (the reference's
+ * block shape, main.cu:351-352), numbered row-major from the bottom-left.  Tile t belongs to part (t % nparts).
+ * nparts == 1: the whole frame, buffers in the reference's row-major layout (pixel_index = j*max_x + i).
+ * nparts  > 1: buffers are tile-major and compact: element (local_tile*64 + ly*8 + lx), local_tile = t / nparts.
+ * rt_part_pixels() gives the element count of such a buffer. */
+typedef struct rt_partition {
+    int32_t part, nparts;
+} rt_partition;
+
+/* ---- library ---------------------------------------------------------------------------------------------- */
+int rt_abi_version(void);
+/* device_count may be NULL. Returns 0 when at least one gfx950 device is usable. */
+int rt_device_check(int* device_count);
+const char* rt_error_string(int code);
+
+/* ---- host side: scene definition ------------------------------------------------------------------------- */
+/* rand_init<<<1,1>>> — main.cu:78-82: curand_init(1984,0,0). Host-side (the world is generated on the host). */
+int rt_rand_init(rt_rand_state* rand_state);
+
+/* create_world<<<1,1>>> — main.cu:146-204.  Fills list[num_spheres] (unfilled slots get RT_MAT_NONE) and *cam,
+ * advances *rand_state exactly as the reference's single device thread does; *num_created = 4 + k*k filled slots. */
+int rt_create_world(rt_sphere* list, int num_spheres, float sphere_radius, rt_camera* cam, int nx, int ny,
+                    rt_rand_state* rand_state, int precision, int* num_created);
+
+/* camera::camera — camera.h:22-44 (vfov in degrees). */
+int rt_camera_init(rt_camera* cam, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,
+                   float aspect, float aperture, float focus_dist, int precision);
+
+/* Describes list + camera for the device: replaces the cudaMalloc'ed d_list/d_world/d_camera (main.cu:393-401).
+ * Host-only; the device copy is made by rt_world_upload. */
+int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam, int precision, rt_world** out);
+/* Creates the device buffers now (otherwise the first render/trace using the handle does it; call this before
+ * capturing launches into a hipGraph, since it allocates). */
+int rt_world_upload(rt_world* world);
+/* free_world<<<1,1>>> + cudaFree — main.cu:206-219, :464-466. */
+int rt_free_world(rt_world* world);
+
+/* buildOctree — acceleration_structure.h:195-217 (host, serial); the upload of main.cu:413-417 is rt_octree_upload.
+ * spheres_per_leaf is SPHERES_PER_LEAF (acceleration_structure.h:15, reference value 30). */
+int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_leaf, int precision, rt_octree** out);
+int rt_octree_upload(rt_octree* octree);   /* the cudaMalloc + cudaMemcpy of main.cu:413-417; implicit on first use */
+int rt_free_octree(rt_octree* octree);
+int rt_octree_flat_info(const rt_octree* octree, int* n_nodes, int* n_entries);   /* traversal copy: nodes used, bucket entries kept */
+/* reference-layout view of the built tree (for parity checks): counts[0..leafCount), indices[leafCount*spl] */
+int rt_octree_info(const rt_octree* octree, int* node_count, int* leaf_count, int* spheres_per_leaf,
+                   int* dropped_full, int* dropped_outside);
+int rt_octree_nodes(const rt_octree* octree, rt_octnode* out_nodes /* [RT_OCTREE_MAX_NODES] */);
+int rt_octree_leaves(const rt_octree* octree, int32_t* counts, int32_t* indices);
+
+/* ---- device side: the hot path ----------------------------------------------------------------------------- */
+/* number of elements (pixels) of a buffer for this partition of a max_x x max_y frame */
+int64_t rt_part_pixels(int max_x, int max_y, rt_partition part);
+
+/* render_init<<<blocks,threads>>> — main.cu:84-94: curand_init(1984 + pixel_index, 0, 0) per pixel. */
+int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partition part, void* stream);
+
+/* render<<<blocks,threads>>> — main.cu:96-117.  fb: device buffer of vec3 (3 x float, or 3 x binary16 in FP16 mode).
+ * d_octree == NULL selects the hitable_list path (USE_OCTREE undefined, main.cu:54). */
+int rt_render(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state,
+              const rt_octree* d_octree, rt_partition part, void* stream);
+
+/* render_progressive<<<blocks,threads>>> — main.cu:119-142: one sample per call, fb = col (current_sample == 1) or fb += col. */
+int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, const rt_world* world,
+                          rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream);
+
+/* Reassemble a full row-major frame from nparts tile-major part buffers laid out back to back, each padded to
+ * rt_part_pixels(max_x,max_y,{0,nparts}) elements (the layout an all-gather of the parts produces). */
+int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream);
+
+/* hitTree (acceleration_structure.h:319-342) / hitable_list::hit (hitable_list.h:16-31) for a batch of rays:
+ * d_rays = n x 6 floats (origin, direction) on the device, d_out = n records on the device. t in (0.001, FLT_MAX). */
+int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float* d_rays, int64_t n,
+                  rt_hit_record* d_out, void* stream);
+
+/* ---- host side: output --------------------------------------------------------------------------------------- */
+/* output_to_stream — main.cu:321-333: ASCII P3, top row first, int(255.99*c).  fb is a HOST buffer.
+ * path == NULL writes to stdout (output mode 0), otherwise to the file (output mode 3 uses "output.ppm"). */
+int rt_write_ppm(const char* path, int nx, int ny, const void* fb, int precision);
+/* same bytes into memory; returns the length, or the required length when cap is too small / out is NULL */
+int64_t rt_format_ppm(int nx, int ny, const void* fb, int precision, char* out, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

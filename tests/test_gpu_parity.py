@@ -1,0 +1,194 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same seeds.
+Bar: bit-exact for fp32 (hit records, float framebuffers, RNG state, PPM bytes)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleScene, ppm_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def gpu_render(rt, torch, W, O, nx, ny, ns, part=None):
+    part = part or rt.WHOLE
+    st = rt.alloc_rand_state(nx, ny, part)
+    fb = rt.alloc_fb(nx, ny, part)
+    rt.render_init(nx, ny, st, part)
+    rt.render(fb, nx, ny, ns, W, st, O, part)
+    torch.cuda.synchronize()
+    return fb, st
+
+
+def random_rays(n, seed):
+    """rays that exercise the scene: origins around/inside the sphere field, at the camera, far away on the ground;
+    directions random, some axis-aligned (zero components -> inf/NaN slab arithmetic)."""
+    rng = np.random.default_rng(seed)
+    o = np.empty((n, 3), np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    k = n // 4
+    o[:k] = rng.uniform([-11, 0, -11], [11, 2, 11], (k, 3))
+    o[k:2 * k] = np.array([13, 2, 3], np.float32) + rng.normal(scale=0.05, size=(k, 3))
+    tgt = rng.uniform([-11, 0, -11], [11, 0.3, 11], (k, 3))
+    d[k:2 * k] = tgt - o[k:2 * k]
+    o[2 * k:3 * k] = rng.uniform([-300, 0, -300], [300, 40, 300], (k, 3))
+    tgt = rng.uniform([-11, 0, -11], [11, 1, 11], (k, 3))
+    d[2 * k:3 * k] = tgt - o[2 * k:3 * k]
+    o[3 * k:] = rng.uniform([-12, -0.5, -12], [12, 3, 12], (n - 3 * k, 3))
+    # axis-aligned / zero-component directions
+    z = rng.integers(0, n, n // 50)
+    d[z, rng.integers(0, 3, z.size)] = 0.0
+    z = rng.integers(0, n, n // 100)
+    d[z] = 0.0
+    d[z, rng.integers(0, 3, z.size)] = rng.choice([-1.0, 1.0], z.size)
+    return np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
+
+
+@pytest.mark.parametrize("n,spl", [(22, 30), (500, 30), (10000, 32)])
+@pytest.mark.parametrize("tree", [False, True])
+def test_trace_hit_records(rt, cuda, n, spl, tree):
+    """hitTree / hitable_list::hit: per-ray hit records bit-identical to the oracle."""
+    torch = cuda
+    nrays = 200_000 if n <= 500 else 60_000
+    rays = random_rays(nrays, 1234 + n)
+    W = rt.World(n, 1200, 800)
+    O = rt.Octree(W, spl) if tree else None
+    d_rays = torch.from_numpy(rays).cuda()
+    d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+    rt.trace_rays(W, O, d_rays, nrays, d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(rt.hit_record_dtype)
+    ref = OracleScene(n, 1200, 800, use_octree=tree, spl=spl).trace(rays, mode=2 if tree else 1)
+    assert np.array_equal(got["sphere"], ref["sphere"])
+    assert ref["hit"].sum() > nrays // 20
+    assert np.array_equal(bits(got["t"]), bits(ref["t"]))
+    assert np.array_equal(bits(got["p"]), bits(ref["p"]))
+    assert np.array_equal(bits(got["normal"]), bits(ref["normal"]))
+
+
+@pytest.mark.parametrize("n,nx,ny,ns,tree,spl", [
+    (22, 64, 36, 4, False, 30), (22, 64, 36, 4, True, 30),
+    (500, 64, 36, 4, False, 30), (500, 61, 35, 3, True, 30),      # ragged: not a multiple of the 8x8 tile
+    (10000, 48, 32, 2, True, 32), (10000, 48, 32, 2, False, 32),
+])
+def test_render_small_frames(rt, cuda, n, nx, ny, ns, tree, spl):
+    """render(): float framebuffer and written-back RNG state bit-identical to the oracle."""
+    torch = cuda
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, spl) if tree else None
+    fb, st = gpu_render(rt, torch, W, O, nx, ny, ns)
+    S = OracleScene(n, nx, ny, use_octree=tree, spl=spl)
+    ref, ref_st = S.render(ns, nthreads=8)
+    got = fb.cpu().numpy().reshape(ny, nx, 3)
+    assert np.array_equal(bits(got), bits(ref))
+    got_st = st.cpu().numpy().view(np.uint32).reshape(-1, 12)
+    assert np.array_equal(got_st[:, :6], ref_st[:, :6])
+
+
+def test_c1_ppm_md5(rt, cuda):
+    """BASELINE config 1 (400x225, 4 spp, N=22, list): PPM bytes equal the oracle's and the SURVEY §8c probe md5."""
+    torch = cuda
+    nx, ny, ns = 400, 225, 4
+    W = rt.World(22, nx, ny)
+    fb, _ = gpu_render(rt, torch, W, None, nx, ny, ns)
+    got = fb.cpu().numpy().reshape(ny, nx, 3)
+    ppm = rt.format_ppm(got, nx, ny)
+    assert hashlib.md5(ppm).hexdigest() == "bb5ebdd40d476c6a48e7de6a3af3e3ed"
+    ref, _ = OracleScene(22, nx, ny).render(ns, nthreads=8)
+    assert ppm == ppm_bytes(ref)
+
+
+def test_render_init_states(rt, cuda):
+    torch = cuda
+    nx, ny = 70, 33
+    st = rt.alloc_rand_state(nx, ny)
+    rt.render_init(nx, ny, st)
+    torch.cuda.synchronize()
+    got = st.cpu().numpy().view(np.uint32).reshape(-1, 12)
+    ref = OracleScene(22, nx, ny).render_init()
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+def test_partition_assemble_equals_whole(rt, cuda, nparts):
+    """tile partition (multi-GPU split) + rt_assemble reproduces the single-call frame bit for bit."""
+    torch = cuda
+    nx, ny, ns, n = 100, 52, 3, 500
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, 30)
+    whole, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
+    per = rt.part_pixels(nx, ny, rt.Partition(0, nparts))
+    parts = torch.zeros(nparts * per * 3, dtype=torch.float32, device="cuda")
+    for p in range(nparts):
+        part = rt.Partition(p, nparts)
+        fb, _ = gpu_render(rt, torch, W, O, nx, ny, ns, part)
+        parts[p * per * 3: p * per * 3 + fb.numel()] = fb
+    full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda")
+    rt.assemble(full, parts, nx, ny, nparts)
+    torch.cuda.synchronize()
+    assert torch.equal(full.view(torch.int32), whole.view(torch.int32))
+
+
+def test_render_progressive(rt, cuda):
+    """render_progressive: accumulation and RNG continuation equal the oracle's after 3 passes."""
+    torch = cuda
+    nx, ny, n = 56, 40, 500
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, 30)
+    st = rt.alloc_rand_state(nx, ny)
+    fb = rt.alloc_fb(nx, ny)
+    rt.render_init(nx, ny, st)
+    S = OracleScene(n, nx, ny, use_octree=True, spl=30)
+    ref_st = S.render_init()
+    ref = np.zeros((ny, nx, 3), np.float32)
+    for k in range(1, 4):
+        rt.render_progressive(fb, nx, ny, k, W, st, O)
+        S.render_progressive(ref, k, ref_st, nthreads=8)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(fb.cpu().numpy().reshape(ny, nx, 3)), bits(ref))
+    assert np.array_equal(st.cpu().numpy().view(np.uint32).reshape(-1, 12)[:, :6], ref_st[:, :6])
+
+
+def test_full_size_properties_c3(rt, cuda):
+    """BASELINE config 3 at full size (1200x800x64, N=10000, octree SPL 32): properties that do not need the whole
+    oracle frame — sampled rows equal the oracle bit for bit, the run is deterministic, the partitioned render
+    equals the whole one, and the RNG state after render(64) equals the state after 64 progressive passes on
+    a sub-frame."""
+    torch = cuda
+    nx, ny, ns, n, spl = 1200, 800, 64, 10000, 32
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, spl)
+    fb, st = gpu_render(rt, torch, W, O, nx, ny, ns)
+    fb2, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
+    assert torch.equal(fb.view(torch.int32), fb2.view(torch.int32))
+    got = fb.cpu().numpy().reshape(ny, nx, 3)
+    assert np.isfinite(got).all() and got.min() >= 0.0 and got.max() <= 1.0
+    S = OracleScene(n, nx, ny, use_octree=True, spl=spl)
+    for row in (3, 250, 431, 797):
+        ref, _ = S.render(ns, row0=row, rows=1, nthreads=1)
+        assert np.array_equal(bits(got[row]), bits(ref[0])), "row %d differs" % row
+    nparts = 4
+    per = rt.part_pixels(nx, ny, rt.Partition(0, nparts))
+    parts = torch.zeros(nparts * per * 3, dtype=torch.float32, device="cuda")
+    for p in range(nparts):
+        f, _ = gpu_render(rt, torch, W, O, nx, ny, ns, rt.Partition(p, nparts))
+        parts[p * per * 3: p * per * 3 + f.numel()] = f
+    full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda")
+    rt.assemble(full, parts, nx, ny, nparts)
+    torch.cuda.synchronize()
+    assert torch.equal(full.view(torch.int32), fb.view(torch.int32))
+
+
+def test_list_equals_octree_c2_scene(rt, cuda):
+    """with fp32 the octree image equals the linear-list image (N=500, full width, 8 spp)."""
+    torch = cuda
+    nx, ny, ns, n = 1200, 800, 8, 500
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, 30)
+    a, _ = gpu_render(rt, torch, W, None, nx, ny, ns)
+    b, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
