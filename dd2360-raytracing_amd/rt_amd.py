@@ -75,6 +75,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RtError("librt_amd.so is not built (%s): run __graft_entry__.build() / make -C dd2360-raytracing_amd" % LIB_PATH)
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so (same soname as /opt/rocm's).  Import it
+        # first so that librt_amd.so's NEEDED libamdhip64.so.7 resolves to the copy torch already mapped; two runtimes
+        # in one process leave the second one without devices (hipErrorNoDevice).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             L = C.CDLL(LIB_PATH)
         except OSError as e:

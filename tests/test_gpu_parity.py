@@ -166,7 +166,10 @@ def test_full_size_properties_c3(rt, cuda):
     fb2, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
     assert torch.equal(fb.view(torch.int32), fb2.view(torch.int32))
     got = fb.cpu().numpy().reshape(ny, nx, 3)
-    assert np.isfinite(got).all() and got.min() >= 0.0 and got.max() <= 1.0
+    # NaN pixels are legitimate reference semantics (dielectric::scatter takes sqrt of a negative number,
+    # material.h:95) — they must simply match the oracle bit for bit like everything else.
+    finite = got[np.isfinite(got)]
+    assert finite.min() >= 0.0 and finite.max() <= 1.0 and finite.size > 0.99 * got.size
     S = OracleScene(n, nx, ny, use_octree=True, spl=spl)
     for row in (3, 250, 431, 797):
         ref, _ = S.render(ns, row0=row, rows=1, nthreads=1)
