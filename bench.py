@@ -12,7 +12,6 @@ Prints ONE JSON line on rank 0.  --config c2|c3 selects another BASELINE config 
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -28,14 +27,6 @@ CONFIGS = {
 }
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate, spec
 PEAK_HBM_GBS = 8000.0
-
-
-def scaled_frame(nx, ny, n):
-    """frame with the same aspect and ~n times the pixels (weak scaling)"""
-    if n == 1:
-        return nx, ny
-    s = math.sqrt(n)
-    return int(round(nx * s)), int(round(ny * s))
 
 
 def cpu_baseline(cfg, rt_cores, use_octree, rows, spp):
@@ -74,6 +65,7 @@ def main():
 
     import torch
     import rt_amd as rt
+    import rt_dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +84,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
-    nx, ny = scaled_frame(cfg["nx"], cfg["ny"], world)
+    nx, ny = rt_dist.scaled_frame(cfg["nx"], cfg["ny"], world)
     spp = cfg["spp"]
     part = rt.Partition(rank, world)
 
@@ -104,7 +96,6 @@ def main():
     per = rt.part_pixels(nx, ny, rt.Partition(0, world))          # padded part size (largest part)
     if world > 1:
         send = torch.zeros(per * 3, dtype=torch.float32, device="cuda")
-        gathered = [torch.zeros(per * 3, dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
         parts = torch.zeros(world * per * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
         full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
 
@@ -121,7 +112,7 @@ def main():
             ev.append((e0, e1))
         if world > 1:
             send[: fb.numel()].copy_(fb)
-            dist.gather(send, gathered, dst=0)                  # the single framebuffer exchange over xGMI
+            gathered = rt_dist.gather_parts(dist, send, rank, world, dst=0)   # the single framebuffer exchange over xGMI
             if rank == 0:
                 torch.cat(gathered, out=parts)
                 rt.assemble(full, parts, nx, ny, world)

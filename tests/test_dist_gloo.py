@@ -1,0 +1,101 @@
+"""N>1 path on CPU (not gpu): two gloo ranks split a frame by the round-robin tile rule, gather the compact part
+buffers with the same rt_dist.gather_parts call bench.py uses over RCCL, and rank 0 reassembles the frame.
+The renderer is replaced by a pixel-id fill (the render itself needs a GPU); a numpy restatement of rt_assemble's
+index arithmetic (tests only) checks that every pixel of the frame arrives exactly once at the right place."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
+
+
+def local_pixel_ids(nx, ny, part, nparts, padded):
+    """tile-major compact buffer of pixel_index values for one part (-1 = padding / outside the frame)"""
+    tx, ty = (nx + 7) // 8, (ny + 7) // 8
+    buf = np.full(padded, -1, np.int64)
+    lt = 0
+    for t in range(part, tx * ty, nparts):
+        x0, y0 = (t % tx) * 8, (t // tx) * 8
+        for lane in range(64):
+            i, j = x0 + (lane & 7), y0 + (lane >> 3)
+            if i < nx and j < ny:
+                buf[lt * 64 + lane] = j * nx + i
+        lt += 1
+    return buf
+
+
+def assemble_numpy(parts, nx, ny, nparts, per):
+    """numpy restatement of k_assemble (tests only)"""
+    tx, ty = (nx + 7) // 8, (ny + 7) // 8
+    full = np.full(nx * ny, -7, np.int64)
+    for t in range(tx * ty):
+        for lane in range(64):
+            i, j = (t % tx) * 8 + (lane & 7), (t // tx) * 8 + (lane >> 3)
+            if i < nx and j < ny:
+                full[j * nx + i] = parts[(t % nparts) * per + (t // nparts) * 64 + lane]
+    return full
+
+
+def _worker(rank, world, port, nx, ny, q):
+    import torch
+    import torch.distributed as dist
+    import rt_dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per = rt_dist.padded_part_pixels(nx, ny, world)
+        mine = rt_dist.part_pixels(nx, ny, rank, world)
+        ids = local_pixel_ids(nx, ny, rank, world, per)
+        assert (ids[mine:] == -1).all()
+        send = torch.from_numpy(ids.astype(np.float64))
+        got = rt_dist.gather_parts(dist, send, rank, world, dst=0)
+        ok = True
+        if rank == 0:
+            parts = torch.cat(got).numpy().astype(np.int64)
+            full = assemble_numpy(parts, nx, ny, world, per)
+            ok = bool(np.array_equal(full, np.arange(nx * ny)))
+        else:
+            ok = got is None
+        dist.barrier()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nx,ny", [(100, 52), (61, 35)])
+def test_two_rank_tile_split_gather_assemble(nx, ny):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nx, ny, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_partition_sizes_match_library(rt):
+    import rt_dist
+    for nx, ny in ((1200, 800), (61, 35), (3394, 2263)):
+        for nparts in (1, 2, 4, 8):
+            for p in range(nparts):
+                assert rt_dist.part_pixels(nx, ny, p, nparts) == rt.part_pixels(nx, ny, rt.Partition(p, nparts))
+            assert rt_dist.padded_part_pixels(nx, ny, nparts) == rt.part_pixels(nx, ny, rt.Partition(0, nparts))
+
+
+def test_scaled_frame_keeps_pixels_per_gpu():
+    import rt_dist
+    for n in (1, 2, 4, 8):
+        nx, ny = rt_dist.scaled_frame(1200, 800, n)
+        assert abs(nx * ny / (n * 960000) - 1) < 0.002 and abs(nx / ny - 1.5) < 0.002

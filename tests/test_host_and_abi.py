@@ -1,0 +1,106 @@
+"""CPU tests of the product's host side (not gpu): the C-ABI library loads and exports every symbol of
+include/rt_amd.h, and its host-only entry points (world generation, camera, octree build, PPM writer, partition
+arithmetic) agree bit for bit with the oracle.  No compute entry point is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleScene, ppm_bytes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_abi_exports_every_declared_symbol(rt):
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(rt.SYMBOLS), "binding and header disagree: %s" % (declared ^ set(rt.SYMBOLS))
+    L = rt.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rt_abi_version() == 1
+
+
+def test_pod_sizes_match_reference_structs(rt):
+    # curandState 48, camera 88, OctNode 60
+    assert rt.rand_state_dtype.itemsize == 48 and rt.camera_dtype.itemsize == 88 and rt.octnode_dtype.itemsize == 60
+
+
+def test_compute_calls_reject_bad_arguments(rt):
+    L = rt.lib()
+    assert L.rt_render(None, 0, 0, 0, None, None, None, rt.WHOLE, None) == -1
+    assert L.rt_render_init(8, 8, None, rt.WHOLE, None) == -1
+    assert L.rt_part_pixels(8, 8, rt.Partition(3, 2)) == -1
+    assert L.rt_create_world(None, 4, 0.1, None, 1, 1, None, 0, None) == -1
+    assert rt.lib().rt_error_string(-1) == b"invalid argument"
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("n,spl", [(22, 30), (500, 30), (8000, 30), (10000, 32)])
+def test_world_camera_octree_match_oracle(rt, precision, n, spl):
+    W = rt.World(n, 1200, 800, precision=precision)
+    O = rt.Octree(W, spl)
+    S = OracleScene(n, 1200, 800, fp16=bool(precision), use_octree=True, spl=spl)
+    geom, mat, kind = S.spheres()
+    sp = W.spheres
+    assert np.array_equal(u32(sp["center"]), u32(geom[:, :3])) and np.array_equal(u32(sp["radius"]), u32(geom[:, 3]))
+    assert np.array_equal(sp["material"], kind)
+    assert np.array_equal(u32(sp["albedo"]), u32(mat[:, :3])) and np.array_equal(u32(sp["param"]), u32(mat[:, 3]))
+    assert W.created == S.info()["real"]
+    assert np.array_equal(u32(W.camera).ravel(), u32(S.camera()))
+    assert np.array_equal(u32(W.rand_state).ravel()[:6], S.world_rng()[:6])        # *rand_state = local_rand_state
+    t = S.octree()
+    nodes = O.nodes()
+    counts, idx = O.leaves()
+    assert np.array_equal(nodes["level"], t["level"]) and np.array_equal(u32(nodes["aabb"]), u32(t["box"]))
+    assert np.array_equal(nodes["children"], t["children"])
+    assert np.array_equal(counts, t["counts"]) and np.array_equal(idx, t["indices"])
+    info, oinfo = O.info(), S.info()
+    assert info["node_count"] == oinfo["node_count"] and info["leaf_count"] == oinfo["leaf_count"]
+    assert info["dropped_full"] == oinfo["dropped_full"]
+    # traversal copy: every used node once, every non-ghost entry once
+    ghosts = set(np.nonzero(kind == -1)[0].tolist())
+    live_entries = sum(1 for l in range(1, len(counts)) for k in range(counts[l]) if idx[l, k] not in ghosts)
+    assert info["flat_nodes"] == info["node_count"] and info["flat_entries"] == live_entries
+
+
+def test_camera_init_matches_create_world(rt):
+    W = rt.World(22, 1200, 800)
+    cam = rt.camera_init((13, 2, 3), (0, 0, 0), (0, 1, 0), 30.0, np.float32(1200) / np.float32(800), np.float32(0.1), 10.0)
+    assert np.array_equal(u32(cam), u32(W.camera))
+
+
+def test_ppm_writer_matches_oracle(rt, tmp_path):
+    rng = np.random.default_rng(1)
+    fb = rng.uniform(0, 1, (9, 13, 3)).astype(np.float32)
+    fb[0, 0] = [0.0, 1.0, 0.999999]
+    assert rt.format_ppm(fb, 13, 9) == ppm_bytes(fb)
+    p = tmp_path / "o.ppm"
+    assert rt.lib().rt_write_ppm(str(p).encode(), 13, 9, fb.ctypes.data, 0) == 0
+    assert p.read_bytes() == ppm_bytes(fb)
+    # fp16 framebuffer (3 x binary16 per pixel)
+    h = fb.astype(np.float16)
+    assert rt.format_ppm(h, 13, 9, precision=1) == ppm_bytes(h.astype(np.float32))
+
+
+def test_partition_arithmetic(rt):
+    for nx, ny in ((1200, 800), (61, 35), (8, 8), (3394, 2263)):
+        tiles = ((nx + 7) // 8) * ((ny + 7) // 8)
+        assert rt.part_pixels(nx, ny) == nx * ny
+        for nparts in (2, 3, 8):
+            sizes = [rt.part_pixels(nx, ny, rt.Partition(p, nparts)) for p in range(nparts)]
+            assert sum(sizes) == tiles * 64 and max(sizes) == sizes[0] and max(sizes) - min(sizes) <= 64
+
+
+def test_reference_host_program_builds():
+    # rt_main (the main.cu counterpart) is part of build(); it needs a GPU to run, only its presence is checked here
+    import __graft_entry__
+    if not os.path.exists(os.path.join(ROOT, "dd2360-raytracing_amd", "rt_main")):
+        __graft_entry__.build()
+    assert os.access(os.path.join(ROOT, "dd2360-raytracing_amd", "rt_main"), os.X_OK)

@@ -1,0 +1,157 @@
+"""CPU tests of the ORACLE itself (not gpu): the externally pinned values recorded in SURVEY.md §8c / App. A
+(produced at survey time from the reference's own headers), the frozen golden vectors, and the oracle's
+binary16 arithmetic against numpy."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleScene, lib, ppm_bytes, xorwow_stream
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_xorwow_known_answers():
+    # seed 1984 state and first uniforms, seed 1985 first uniforms
+    init, u = xorwow_stream(1984, 4)
+    assert [int(x) for x in init[:6]] == [0x0e2ad815, 0x3b8fc912, 0x21a9ae18, 0xf8a42704, 0xdcd8f87c, 0x348c3b16]
+    assert [int(x) for x in u.view(np.uint32)] == [0x3e48b09e, 0x3ee873b3, 0x3eb7ce17, 0x3f39620a]
+    _, u = xorwow_stream(1985, 4)
+    assert [int(x) for x in u.view(np.uint32)] == [0x3eb57405, 0x3f5a9bd8, 0x3ecb5bc7, 0x3f78538f]
+    g = np.load(os.path.join(GOLD, "xorwow.npz"))
+    for seed in (1984, 1985, 1984 + 400 * 225 - 1):
+        init, u = xorwow_stream(seed, 16)
+        assert np.array_equal(init[:6], g["xorwow_%d_state" % seed])
+        assert np.array_equal(u.view(np.uint32), g["xorwow_%d_uniform" % seed].view(np.uint32))
+
+
+def test_uniform_range():
+    # curand_uniform is (0, 1]: x = 0 -> 2^-33, x = 0xffffffff -> 1.0
+    L = lib()
+    st = np.zeros(12, np.uint32)
+    L.orc_xorwow_init(st.ctypes.data, 5)
+    u = np.array([L.orc_uniform(st.ctypes.data) for _ in range(20000)], np.float32)
+    assert u.min() > 0.0 and u.max() <= 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("n,real,draws", [(22, 20, 130), (500, 500, None), (8000, 8000, None), (10000, 9805, 82305), (100000, 99860, None)])
+def test_world_counts(n, real, draws):
+    # filled slots (ghosts = n - real) and RNG draws consumed by create_world
+    info = OracleScene(n, 1200, 800).info()
+    assert info["real"] == real
+    if draws is not None:
+        assert info["world_draws"] == draws
+
+
+@pytest.mark.parametrize("n,spl,nodes,leaf_slots,entries,drops", [
+    (22, 30, 114, 81, None, 0), (500, 30, 157, None, None, 0), (8000, 30, 157, 388, 9229, 0), (10000, 32, 157, 438, 11368, 309)])
+def test_octree_counts(n, spl, nodes, leaf_slots, entries, drops):
+    # nodeCount / leafCount (slot 0 unused) / total leaf entries / "leaf nodes full" drops
+    info = OracleScene(n, 1200, 800, use_octree=True, spl=spl).info()
+    assert info["node_count"] == nodes and info["dropped_full"] == drops and info["dropped_outside"] == 0
+    if leaf_slots is not None:
+        assert info["leaf_count"] == leaf_slots
+    if entries is not None:
+        assert info["leaf_entries"] == entries
+
+
+def test_spl_capacity_100k():
+    # N=100 000 needs SPHERES_PER_LEAF >= 320 for zero drops of real spheres (26 drops at 288)
+    assert OracleScene(100000, 3840, 2160, use_octree=True, spl=320).info()["dropped_full"] == 0
+    assert OracleScene(100000, 3840, 2160, use_octree=True, spl=288).info()["dropped_full"] > 0
+
+
+def test_camera_half_height_bits():
+    # half_height = tan(theta/2) = 0x3e8930a3 for vfov 30; vertical = 2*half_height*focus*v
+    cam = OracleScene(22, 1200, 800).camera()
+    hh = np.array([0x3e8930a3], np.uint32).view(np.float32)[0]
+    v = cam[15:18]
+    vertical = cam[9:12]
+    assert np.array_equal((np.float32(np.float32(2.0) * hh) * np.float32(10.0) * v).view(np.uint32), vertical.view(np.uint32))
+    assert cam[21] == np.float32(np.float32(0.1) / np.float32(2.0))
+
+
+def test_c1_ppm_md5_list_and_octree():
+    # BASELINE config 1; SURVEY §8c provisional md5 (list and octree identical)
+    want = open(os.path.join(GOLD, "c1_ppm.md5")).read().strip()
+    assert want == "bb5ebdd40d476c6a48e7de6a3af3e3ed"
+    fb, _ = OracleScene(22, 400, 225).render(4, nthreads=8)
+    assert hashlib.md5(ppm_bytes(fb)).hexdigest() == want
+    fb2, _ = OracleScene(22, 400, 225, use_octree=True, spl=30).render(4, nthreads=8)
+    assert np.array_equal(fb.view(np.uint32), fb2.view(np.uint32))
+
+
+def test_golden_worlds_and_octrees():
+    g = np.load(os.path.join(GOLD, "worlds.npz"))
+    for fp16 in (0, 1):
+        for n, spl in ((22, 30), (500, 30), (10000, 32)):
+            S = OracleScene(n, 1200, 800, fp16=bool(fp16), use_octree=True, spl=spl)
+            tag = "%s_n%d" % ("fp16" if fp16 else "fp32", n)
+            geom, mat, kind = S.spheres()
+            sha = hashlib.sha256(geom.tobytes() + mat.tobytes() + kind.tobytes()).digest()
+            assert np.array_equal(np.frombuffer(sha, np.uint8), g[tag + "_geom_sha"])
+            assert np.array_equal(S.camera().view(np.uint32), g[tag + "_camera"].view(np.uint32))
+            t = S.octree()
+            h = hashlib.sha256()
+            for key in ("level", "box", "children", "counts", "indices"):
+                h.update(np.ascontiguousarray(t[key]).tobytes())
+            assert np.array_equal(np.frombuffer(h.digest(), np.uint8), g[tag + "_octree_sha"])
+
+
+def test_golden_hits_and_list_tree_agree():
+    g = np.load(os.path.join(GOLD, "hits.npz"))
+    for n, spl in ((22, 30), (500, 30), (10000, 32)):
+        S = OracleScene(n, 1200, 800, use_octree=True, spl=spl)
+        r = g["n%d_rays" % n]
+        for mode, name in ((1, "list"), (2, "tree")):
+            h = S.trace(r, mode)
+            assert np.array_equal(h["sphere"], g["n%d_%s_sphere" % (n, name)])
+            assert np.array_equal(h["t"].view(np.uint32), g["n%d_%s_t" % (n, name)].view(np.uint32))
+            assert np.array_equal(h["normal"].view(np.uint32), g["n%d_%s_normal" % (n, name)].view(np.uint32))
+
+
+def test_golden_frames():
+    g = np.load(os.path.join(GOLD, "frames.npz"))
+    for name in ("n22_list", "n500_list", "n500_tree", "n10000_tree", "n9805_tree_fp16", "n500_list_fp16"):
+        n, nx, ny, ns, tree, spl, fp16 = [int(x) for x in g[name + "_cfg"]]
+        fb, st = OracleScene(n, nx, ny, fp16=bool(fp16), use_octree=bool(tree), spl=spl).render(ns, nthreads=8)
+        assert np.array_equal(fb.view(np.uint32), g[name + "_fb"].view(np.uint32)), name
+        assert np.array_equal(st[:, :6], g[name + "_rng"]), name
+
+
+def test_rows_are_independent():
+    # pixels are independent units keyed by absolute pixel_index: a row range renders the same bits as the full frame
+    S = OracleScene(500, 40, 24, use_octree=True, spl=30)
+    full, _ = S.render(3, nthreads=4)
+    part, _ = S.render(3, row0=7, rows=5, nthreads=2)
+    assert np.array_equal(full[7:12].view(np.uint32), part.view(np.uint32))
+
+
+def test_half_conversion_against_numpy():
+    L = lib()
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([
+        rng.normal(size=20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 20000).astype(np.float32),
+        np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, 6.0975e-5, np.inf, -np.inf], np.float32),
+        np.arange(2048, dtype=np.float32) / np.float32(2048.0) + np.float32(1.0),
+    ]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16)
+    got = np.array([L.orc_f32_to_f16(float(v)) for v in vals], np.uint16)
+    assert np.array_equal(got, want.view(np.uint16))
+    allh = np.arange(65536, dtype=np.uint32).astype(np.uint16)
+    back = np.array([L.orc_f16_to_f32(int(h)) for h in allh], np.float32)
+    ref = allh.view(np.float16).astype(np.float32)
+    ok = (back.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(back) & np.isnan(ref))
+    assert ok.all()
+
+
+def test_fp16_mode_sanity():
+    # USE_FP16: the r=1000 ground sphere overflows binary16 (1000*1000 > 65504) and is never hit;
+    # the image is far from the fp32 one (the reference measured PSNR 12.4 dB, evaluations.ipynb:1076)
+    a, _ = OracleScene(500, 96, 64).render(4, nthreads=8)
+    b, _ = OracleScene(500, 96, 64, fp16=True).render(4, nthreads=8)
+    mse = float(np.mean((np.clip(a, 0, 1) - np.clip(np.nan_to_num(b), 0, 1)) ** 2))
+    psnr = 10 * np.log10(1.0 / mse)
+    assert 6.0 < psnr < 20.0
