@@ -1,0 +1,111 @@
+// rt_accel.h — host-side construction of the candidate-culling structure used by the fast closest-hit path.
+//
+// WHY IT IS EXACT (DESIGN.md §5.3 has the derivation).  The reference finds, for a ray, the closest hit among the
+// spheres stored in the level-3 cells its traversal visits (acceleration_structure.h:276-304).  Testing FEWER spheres
+// gives the same record as long as every skipped sphere is one whose float sphere::hit (sphere.h:17-46) cannot
+// succeed with a smaller t.  For binary32 arithmetic in the reference's operation order,
+//     discriminant > 0   ==>   dist(centre, line)^2  <  r^2 + 16.1 u |o - c|^2        (u = 2^-24)
+// so a sphere whose ball of radius R = sqrt(r^2 + K2) (K2 covers 16.1 u |o-c|^2 for every ray origin inside the "near
+// zone") is missed by the ray's line cannot be hit.  The grid below registers each small sphere in every (x,z) cell its
+// ball, grown by a rasterisation slack, can touch; the kernel walks the cells the ray's (x,z) projection crosses.
+// Rays outside the near zone, rays with a zero direction component, and exact-t ties fall back to the reference scan.
+#pragma once
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include "rt_device.h"
+
+namespace rt {
+
+struct AccelHost {
+    std::vector<float4> large_hot; std::vector<int32_t> large_id;
+    std::vector<int32_t> cs_x, cs_z, id_x, id_z; std::vector<float4> hot_x, hot_z;
+    std::vector<int32_t> memb_start, memb_cell;
+    DevAccel p{};
+};
+
+// constants of the exactness argument
+static const double kZone = 24.0;          // near zone: |o - (0,1,0)| <= kZone
+static const double kCentreBound = 17.5;   // grid spheres have |c - (0,1,0)| <= this (root box grown by the radius)
+static const double kSlack = 2e-3;         // rasterisation slack (absorbs float error of the walk, ~1e-5)
+// 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
+static inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
+// inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
+static inline double accel_Rp(double r2) { return std::sqrt(r2 * (1.0 + 1e-6) + accel_K2()) + 1e-5 + kSlack; }
+
+// nodes/ent_id: the pre-order traversal copy; geom_r2(i) gives (cx,cy,cz,r^2) of world-list index i
+inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const std::vector<int32_t>& ent_id, const std::vector<float4>& ent_hot, int n_world) {
+    // 1. membership: sphere -> level-3 nodes (pre-order index) that hold it
+    A.memb_start.assign((size_t)n_world + 1, 0);
+    for (size_t k = 0; k < nodes.size(); ++k)
+        for (int e = nodes[k].first; e < nodes[k].first + nodes[k].count; ++e) A.memb_start[(size_t)ent_id[e] + 1]++;
+    for (int i = 0; i < n_world; ++i) A.memb_start[(size_t)i + 1] += A.memb_start[i];
+    A.memb_cell.assign(A.memb_start[n_world], 0);
+    std::vector<int32_t> fill(A.memb_start.begin(), A.memb_start.end() - 1);
+    std::vector<float4> hot_of((size_t)n_world, make_float4(0, 0, 0, 0));
+    std::vector<char> in_tree((size_t)n_world, 0);
+    for (size_t k = 0; k < nodes.size(); ++k)
+        for (int e = nodes[k].first; e < nodes[k].first + nodes[k].count; ++e) {
+            const int s = ent_id[e];
+            A.memb_cell[fill[s]++] = (int32_t)k;
+            hot_of[s] = ent_hot[e]; in_tree[s] = 1;
+        }
+    // 2. cell size from the median radius of the tree spheres
+    std::vector<double> radii;
+    for (int s = 0; s < n_world; ++s) if (in_tree[s]) radii.push_back(std::sqrt((double)hot_of[s].w));
+    DevAccel& p = A.p;
+    p = DevAccel{};
+    if (radii.empty()) { p.enabled = 0; A.cs_x.assign(2, 0); A.cs_z.assign(2, 0); return; }
+    std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+    const double rmed = radii[radii.size() / 2];
+    double h = 2.0 * accel_Rp(rmed * rmed);
+    h = std::min(1.0, std::max(0.05, h));
+    const double Rlim = 1.5 * h;                               // spheres with R' above this go to the large list
+    const double half = 11.0 + 2.0 * Rlim + 2.0 * h;
+    const int G = (int)std::ceil(2.0 * half / h);
+    const double g0 = -half;
+    p.G = G; p.g0 = (float)g0; p.h = (float)h; p.inv_h = (float)(1.0 / h);
+    // 3. classify + register
+    struct Reg { int s, ix0, ix1, iz0, iz1; };
+    std::vector<Reg> regs;
+    double ylo = 1e30, yhi = -1e30, rmax = 0;
+    for (int s = 0; s < n_world; ++s) {
+        if (!in_tree[s]) continue;
+        const float4 g = hot_of[s];
+        const double Rp = accel_Rp((double)g.w);
+        const double dc = std::sqrt((double)g.x * g.x + ((double)g.y - 1.0) * ((double)g.y - 1.0) + (double)g.z * g.z);
+        const bool inside = (g.x - Rp > g0 + h) && (g.x + Rp < g0 + (G - 1) * h) && (g.z - Rp > g0 + h) && (g.z + Rp < g0 + (G - 1) * h);
+        if (Rp > Rlim || dc > kCentreBound || !inside || !(g.w >= 0.0f)) { A.large_hot.push_back(g); A.large_id.push_back(s); continue; }
+        Reg r; r.s = s;
+        r.ix0 = (int)std::floor((g.x - Rp - g0) / h - 1e-4); r.ix1 = (int)std::floor((g.x + Rp - g0) / h + 1e-4);
+        r.iz0 = (int)std::floor((g.z - Rp - g0) / h - 1e-4); r.iz1 = (int)std::floor((g.z + Rp - g0) / h + 1e-4);
+        r.ix0 = std::max(0, r.ix0); r.iz0 = std::max(0, r.iz0); r.ix1 = std::min(G - 1, r.ix1); r.iz1 = std::min(G - 1, r.iz1);
+        regs.push_back(r);
+        ylo = std::min(ylo, (double)g.y - Rp); yhi = std::max(yhi, (double)g.y + Rp); rmax = std::max(rmax, Rp);
+    }
+    p.n_large = (int)A.large_id.size();
+    const size_t ncell = (size_t)G * G;
+    A.cs_x.assign(ncell + 1, 0); A.cs_z.assign(ncell + 1, 0);
+    for (const Reg& r : regs)
+        for (int ix = r.ix0; ix <= r.ix1; ++ix)
+            for (int iz = r.iz0; iz <= r.iz1; ++iz) { A.cs_x[(size_t)ix * G + iz + 1]++; A.cs_z[(size_t)iz * G + ix + 1]++; }
+    for (size_t c = 0; c < ncell; ++c) { A.cs_x[c + 1] += A.cs_x[c]; A.cs_z[c + 1] += A.cs_z[c]; }
+    const size_t total = (size_t)A.cs_x[ncell];
+    A.hot_x.assign(total, make_float4(0, 0, 0, 0)); A.hot_z.assign(total, make_float4(0, 0, 0, 0));
+    A.id_x.assign(total, 0); A.id_z.assign(total, 0);
+    std::vector<int32_t> fx(A.cs_x.begin(), A.cs_x.end() - 1), fz(A.cs_z.begin(), A.cs_z.end() - 1);
+    for (const Reg& r : regs)
+        for (int ix = r.ix0; ix <= r.ix1; ++ix)
+            for (int iz = r.iz0; iz <= r.iz1; ++iz) {
+                const int a = fx[(size_t)ix * G + iz]++, b = fz[(size_t)iz * G + ix]++;
+                A.hot_x[a] = hot_of[r.s]; A.id_x[a] = r.s;
+                A.hot_z[b] = hot_of[r.s]; A.id_z[b] = r.s;
+            }
+    if (regs.empty()) { ylo = 0; yhi = 0; }
+    p.ylo = (float)(ylo - 1e-4); p.yhi = (float)(yhi + 1e-4); p.rmax = (float)(rmax + 1e-4);
+    p.zone2 = (float)(kZone * kZone);
+    p.enabled = 1;
+}
+
+} // namespace rt

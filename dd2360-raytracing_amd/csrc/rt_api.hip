@@ -9,6 +9,7 @@
 #include <new>
 #include "rt_device.h"
 #include "../host/rt_scene.hpp"
+#include "rt_accel.h"
 
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
@@ -38,8 +39,11 @@ struct rt_octree {
     Octree* host = nullptr;
     bool uploaded = false;
     std::vector<DevNode> h_nodes; std::vector<float4> h_ent_hot; std::vector<int32_t> h_ent_id;
+    AccelHost accel;
+    int traversal = RT_TRAVERSAL_FAST;
     DevTree dev{};
     void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
+    void* d_acc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 template <class T> static int upload(const std::vector<T>& v, void** d) {
@@ -205,6 +209,8 @@ int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_lea
                                                    : buildOctree<float>(list, num_hitables, spheres_per_leaf);
         flatten(*O->host, list, precision, 0, O->h_nodes, O->h_ent_hot, O->h_ent_id);
         O->dev.n_nodes = (int)O->h_nodes.size(); O->dev.n_entries = (int)O->h_ent_id.size();
+        build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, num_hitables);
+        if (precision != RT_PRECISION_FP32) O->accel.p.enabled = 0;      // the error bounds behind the grid are binary32 bounds
     } catch (const std::bad_alloc&) { rt_free_octree(O); return RT_ENOMEM; }
     *out = O;
     return 0;
@@ -216,7 +222,36 @@ int rt_octree_upload(rt_octree* O) {
     int rc;
     if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_hot, &O->d_ent_hot)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
     O->dev.nodes4 = (const float4*)O->d_nodes; O->dev.ent_hot = (const float4*)O->d_ent_hot; O->dev.ent_id = (const int32_t*)O->d_ent_id;
+    AccelHost& A = O->accel;
+    if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_id, &O->d_acc[1])) || (rc = upload(A.cs_x, &O->d_acc[2])) ||
+        (rc = upload(A.cs_z, &O->d_acc[3])) || (rc = upload(A.hot_x, &O->d_acc[4])) || (rc = upload(A.id_x, &O->d_acc[5])) ||
+        (rc = upload(A.hot_z, &O->d_acc[6])) || (rc = upload(A.id_z, &O->d_acc[7])) || (rc = upload(A.memb_start, &O->d_acc[8])) ||
+        (rc = upload(A.memb_cell, &O->d_acc[9]))) return rc;
+    DevAccel& p = A.p;
+    p.large_hot = (const float4*)O->d_acc[0]; p.large_id = (const int32_t*)O->d_acc[1];
+    p.cs_x = (const int32_t*)O->d_acc[2]; p.cs_z = (const int32_t*)O->d_acc[3];
+    p.hot_x = (const float4*)O->d_acc[4]; p.id_x = (const int32_t*)O->d_acc[5];
+    p.hot_z = (const float4*)O->d_acc[6]; p.id_z = (const int32_t*)O->d_acc[7];
+    p.memb_start = (const int32_t*)O->d_acc[8]; p.memb_cell = (const int32_t*)O->d_acc[9];
+    O->dev.acc = p;
     O->uploaded = true;
+    return 0;
+}
+
+// RT_TRAVERSAL_REFERENCE: scan every bucket of every visited level-3 node, exactly like traverseTree.
+// RT_TRAVERSAL_FAST (default): same hit records through the candidate-culling grid (fp32 only; fp16 always scans).
+int rt_octree_set_traversal(rt_octree* O, int mode) {
+    if (!O || (mode != RT_TRAVERSAL_REFERENCE && mode != RT_TRAVERSAL_FAST)) return RT_EINVAL;
+    O->traversal = mode;
+    return 0;
+}
+
+int rt_octree_accel_info(const rt_octree* O, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres) {
+    if (!O) return RT_EINVAL;
+    if (grid_dim) *grid_dim = O->accel.p.G;
+    if (cell_size) *cell_size = O->accel.p.h;
+    if (grid_entries) *grid_entries = (int)O->accel.id_x.size();
+    if (large_spheres) *large_spheres = O->accel.p.n_large;
     return 0;
 }
 
@@ -233,6 +268,7 @@ int rt_free_octree(rt_octree* O) {
     int rc = 0;
     void* bufs[3] = {O->d_nodes, O->d_ent_hot, O->d_ent_id};
     for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
+    for (void* b : O->d_acc) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
     delete O->host;      // the reference frees a new'ed Octree with free() (main.cu:473); here new/delete match
     delete O;
     return rc;
@@ -286,7 +322,8 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
     A.n_local_tiles = (tiles - part.part + part.nparts - 1) / part.nparts;
     A.scene = world->dev;
-    if (d_octree) A.tree = d_octree->dev; else memset(&A.tree, 0, sizeof(A.tree));
+    if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
+    else memset(&A.tree, 0, sizeof(A.tree));
     return (int)launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream);
 }
 
@@ -311,7 +348,9 @@ int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float*
     int rc = rt_world_upload(const_cast<rt_world*>(world));
     if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
     if (rc) return rc;
-    DevTree T; if (d_octree) T = d_octree->dev; else memset(&T, 0, sizeof(T));
+    DevTree T;
+    if (d_octree) { T = d_octree->dev; T.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
+    else memset(&T, 0, sizeof(T));
     return (int)launch_trace(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
 

@@ -32,11 +32,32 @@ struct DevScene {
     rt_camera cam;
 };
 
+// Candidate-culling structure for the fast closest-hit path.  It never decides a hit: it only
+// enumerates a superset of the spheres whose float sphere::hit can succeed; membership of a sphere in a level-3 cell
+// that the reference's traversal visits is then checked with the reference's own slab test.
+struct DevAccel {
+    const float4* large_hot;   // [n_large] (cx,cy,cz,r^2): tree spheres too big (or too far out) for the grid, always tested
+    const int32_t* large_id;   // [n_large]
+    const int32_t* cs_x;       // [G*G+1] cell starts, x-major: cell (ix,iz) at ix*G+iz  -> hot_x / id_x
+    const int32_t* cs_z;       // [G*G+1] cell starts, z-major: cell (ix,iz) at iz*G+ix  -> hot_z / id_z
+    const float4* hot_x; const int32_t* id_x;
+    const float4* hot_z; const int32_t* id_z;
+    const int32_t* memb_start; // [n+1] per world-list index: range in memb_cell
+    const int32_t* memb_cell;  // pre-order node index (DevNode) of each level-3 node whose buckets hold the sphere
+    int32_t n_large, G;
+    float g0, h, inv_h;        // grid origin (same for x and z), cell size
+    float ylo, yhi;            // y-slab covering every grid sphere's inflated ball
+    float rmax;                // largest inflated radius R' of a grid sphere
+    float zone2;               // fast path only for ray origins with |o - (0,1,0)|^2 <= zone2
+    int32_t enabled;
+};
+
 struct DevTree {
     const float4* nodes4;     // [n_nodes*3] DevNode as float4 triples
     const float4* ent_hot;    // [n_entries] (cx, cy, cz, radius*radius) in traversal order
     const int32_t* ent_id;    // [n_entries] index into the world list
     int32_t n_nodes, n_entries;
+    DevAccel acc;
 };
 
 struct RenderArgs {

@@ -104,16 +104,10 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, float& close
     if (best >= 0) best = S.list_id[best];
 }
 
-// hitTree: ground sphere first, then the tree in the reference's depth-first order (pre-order array + skip links).
-// While-while form: every lane first advances to its next non-empty level-3 node that passes the slab test,
-// then all lanes scan their node's entries.
-RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
-    if (S.ground_valid) {
-        const float4 g = S.list_hot[0];
-        int gb = -1;
-        sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
-        if (gb == 0) best = 0;
-    }
+// The reference scan: the tree in the reference's depth-first order (pre-order array + skip links), every bucket entry
+// of every visited level-3 node.  While-while form: each lane first advances to its next non-empty level-3 node that
+// passes the slab test, then scans that node's entries.  `closest`/`best` come in holding the ground-sphere result.
+RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
     int e_best = -1;
     int node = live ? 0 : T.n_nodes;
     const int n_nodes = T.n_nodes;
@@ -139,6 +133,128 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         }
     }
     if (e_best >= 0) best = T.ent_id[e_best];
+}
+
+// sphere::hit reduced to "which t would this sphere offer": the near root if it is > t_min, else the far root if that
+// is > t_min, else none (+inf).  The reference accepts exactly when that value is < closest_so_far (the far root is
+// never below the near root, so a rejected near root in range cannot be followed by an accepted far root).
+RT_DEV float sphere_candidate(const RayF& r, float a, const float4 s) {
+    const float ocx = r.o.x - s.x, ocy = r.o.y - s.y, ocz = r.o.z - s.z;
+    const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
+    const float disc = b * b - a * c;
+    float cand = __builtin_inff();
+    if (disc > 0.0f) {
+        const float sq = sqrtf(disc);
+        const float t1 = (-b - sq) / a;
+        if (t1 > 0.001f) cand = t1;
+        else {
+            const float t2 = (-b + sq) / a;
+            if (t2 > 0.001f) cand = t2;
+        }
+    }
+    return cand;
+}
+
+// Is the sphere stored in a level-3 node that the reference's traversal visits for this ray?  With no zero direction
+// component a node's slab test passing implies all its ancestors' tests pass (their intervals contain the child's),
+// so the node's own test — the reference's arithmetic — decides.
+RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, int sphere) {
+    const int mb = T.acc.memb_start[sphere], me = T.acc.memb_start[sphere + 1];
+    for (int k = mb; k < me; ++k) {
+        const int node = T.acc.memb_cell[k];
+        const float4 n0 = s_nodes[node * 3 + 0];
+        const float4 n1 = s_nodes[node * 3 + 1];
+        if (ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y)) return true;
+    }
+    return false;
+}
+
+RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int id, float& best_t, int& best, bool& tie) {
+    if (cand < best_t) {
+        if (eligible(T, s_nodes, r, id)) { best_t = cand; best = id; }
+    } else if (cand == best_t && id != best && best > 0) {
+        tie = true;                      // two different tree spheres at the same float t: visit order decides -> reference scan
+    }
+}
+
+// Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
+// clipped to the y-slab that holds them, front to back, stopping once the columns lie beyond the best hit.
+// Returns true when the result must be recomputed by the reference scan (exact tie).
+RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, float a, float& best_t, int& best) {
+    const DevAccel& A = T.acc;
+    bool tie = false;
+    for (int k = 0; k < A.n_large; ++k) {
+        const float cand = sphere_candidate(r, a, A.large_hot[k]);
+        offer(T, s_nodes, r, cand, A.large_id[k], best_t, best, tie);
+    }
+    const float slack = 2e-3f;
+    const bool xmajor = fabsf(r.d.x) >= fabsf(r.d.z);
+    const float om = xmajor ? r.o.x : r.o.z, on = xmajor ? r.o.z : r.o.x;
+    const float dm = xmajor ? r.d.x : r.d.z, dn = xmajor ? r.d.z : r.d.x;
+    const int32_t* __restrict__ cs = xmajor ? A.cs_x : A.cs_z;
+    const float4* __restrict__ hot = xmajor ? A.hot_x : A.hot_z;
+    const int32_t* __restrict__ ids = xmajor ? A.id_x : A.id_z;
+    const int G = A.G;
+    const float fG = (float)G;
+    // where the line crosses the planes y = ylo / y = yhi, measured along the major axis
+    const float rmy = dm / r.d.y;
+    const float mA = om + (A.ylo - r.o.y) * rmy, mB = om + (A.yhi - r.o.y) * rmy;
+    float mlo = fminf(mA, mB) - slack, mhi = fmaxf(mA, mB) + slack;
+    const float back = A.rmax + slack;
+    if (dm > 0.0f) mlo = fmaxf(mlo, om - back); else mhi = fminf(mhi, om + back);     // nothing behind the origin matters
+    const float flo = fminf(fmaxf((mlo - A.g0) * A.inv_h, -1.0f), fG), fhi = fminf(fmaxf((mhi - A.g0) * A.inv_h, -1.0f), fG);
+    int ilo = (int)floorf(flo), ihi = (int)floorf(fhi);
+    if (ihi < 0 || ilo > G - 1 || !(mlo <= mhi)) return tie;
+    ilo = max(ilo, 0); ihi = min(ihi, G - 1);
+    const int step = dm > 0.0f ? 1 : -1;
+    int i = dm > 0.0f ? ilo : ihi;
+    const int iend = (dm > 0.0f ? ihi : ilo) + step;
+    const float slope = dn / dm;
+    for (; i != iend; i += step) {
+        const float e0 = A.g0 + (float)i * A.h, e1 = e0 + A.h;
+        if (best >= 0) {                                        // columns entirely beyond the best hit cannot improve it
+            const float pm = om + best_t * dm;
+            const float edge_in = dm > 0.0f ? e0 : e1;
+            if ((edge_in - pm) * (float)step > back) break;
+        }
+        const float n0 = on + (e0 - om) * slope, n1 = on + (e1 - om) * slope;
+        const float nlo = fminf(n0, n1) - slack, nhi = fmaxf(n0, n1) + slack;
+        const float fk0 = fminf(fmaxf((nlo - A.g0) * A.inv_h, -1.0f), fG), fk1 = fminf(fmaxf((nhi - A.g0) * A.inv_h, -1.0f), fG);
+        int k0 = (int)floorf(fk0), k1 = (int)floorf(fk1);
+        if (k1 < 0 || k0 > G - 1) continue;
+        k0 = max(k0, 0); k1 = min(k1, G - 1);
+        int e = cs[i * G + k0];
+        const int e_end = cs[i * G + k1 + 1];
+        for (; e < e_end; ++e) {
+            const float cand = sphere_candidate(r, a, hot[e]);
+            if (cand <= best_t) offer(T, s_nodes, r, cand, ids[e], best_t, best, tie);
+        }
+    }
+    return tie;
+}
+
+// hitTree (acceleration_structure.h:319-342): ground sphere first, then the tree.
+RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
+    if (S.ground_valid) {
+        const float4 g = S.list_hot[0];
+        int gb = -1;
+        sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
+        if (gb == 0) best = 0;
+    }
+    bool slow = live;
+    if (T.acc.enabled) {
+        // preconditions of the exactness argument; any NaN/inf makes a comparison false and sends the ray to the scan
+        const float zx = r.o.x, zy = r.o.y - 1.0f, zz = r.o.z;
+        const bool fast = live && (a >= 9.094947e-13f) && (a <= 1.0995116e12f) && (r.d.x != 0.0f) && (r.d.z != 0.0f)
+                          && (fabsf(r.d.y) >= 9.094947e-13f) && (zx * zx + zy * zy + zz * zz <= T.acc.zone2);
+        slow = live && !fast;
+        if (fast) {
+            const float g_t = closest; const int g_id = best;
+            if (tree_fast(T, s_nodes, r, a, closest, best)) { closest = g_t; best = g_id; slow = true; }
+        }
+    }
+    if (__ballot(slow) != 0ull) tree_scan(T, s_nodes, r, a, slow, closest, best);
 }
 
 // ---------------------------------------------------------------------------------------------------- sampling

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 FP32, FP16 = 0, 1
 MAT_NONE, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = -1, 0, 1, 2
 OCTREE_MAX_NODES = 585
+TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
 
 # PODs of include/rt_amd.h
 rand_state_dtype = np.dtype([("d", "<u4"), ("v", "<u4", 5), ("boxmuller_flag", "<i4"), ("boxmuller_flag_double", "<i4"),
@@ -54,6 +55,8 @@ SYMBOLS = {
     "rt_free_octree": (_i, [_vp]),
     "rt_octree_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rt_octree_flat_info": (_i, [_vp, _vp, _vp]),
+    "rt_octree_set_traversal": (_i, [_vp, _i]),
+    "rt_octree_accel_info": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rt_octree_nodes": (_i, [_vp, _vp]),
     "rt_octree_leaves": (_i, [_vp, _vp, _vp]),
     "rt_part_pixels": (_i64, [_i, _i, Partition]),
@@ -181,6 +184,17 @@ class Octree:
     def upload(self):
         check(lib().rt_octree_upload(self.h), "rt_octree_upload")
         return self
+
+    def set_traversal(self, mode):
+        """TRAVERSAL_REFERENCE (exact bucket scan) or TRAVERSAL_FAST (default, culling grid + fallback)"""
+        check(lib().rt_octree_set_traversal(self.h, mode), "rt_octree_set_traversal")
+        return self
+
+    def accel_info(self):
+        g, n, l = C.c_int(0), C.c_int(0), C.c_int(0)
+        h = C.c_float(0)
+        check(lib().rt_octree_accel_info(self.h, C.byref(g), C.byref(h), C.byref(n), C.byref(l)), "rt_octree_accel_info")
+        return dict(grid_dim=g.value, cell_size=h.value, grid_entries=n.value, large_spheres=l.value)
 
     def info(self):
         v = [C.c_int(0) for _ in range(5)]

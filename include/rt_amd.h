@@ -128,6 +128,14 @@ int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_lea
 int rt_octree_upload(rt_octree* octree);   /* the cudaMalloc + cudaMemcpy of main.cu:413-417; implicit on first use */
 int rt_free_octree(rt_octree* octree);
 int rt_octree_flat_info(const rt_octree* octree, int* n_nodes, int* n_entries);   /* traversal copy: nodes used, bucket entries kept */
+/* How hitTree walks the tree on the device.  Both produce the reference's hit records bit for bit (fp32):
+ * REFERENCE scans every bucket of every visited level-3 node like traverseTree (acceleration_structure.h:276-304);
+ * FAST (default) tests only the spheres a conservative (x,z) grid says the ray can touch and falls back to the scan
+ * for rays it cannot prove.  FP16 trees always use REFERENCE. */
+#define RT_TRAVERSAL_REFERENCE 0
+#define RT_TRAVERSAL_FAST 1
+int rt_octree_set_traversal(rt_octree* octree, int mode);
+int rt_octree_accel_info(const rt_octree* octree, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres);
 /* reference-layout view of the built tree (for parity checks): counts[0..leafCount), indices[leafCount*spl] */
 int rt_octree_info(const rt_octree* octree, int* node_count, int* leaf_count, int* spheres_per_leaf,
                    int* dropped_full, int* dropped_outside);

@@ -49,14 +49,17 @@ def random_rays(n, seed):
 
 
 @pytest.mark.parametrize("n,spl", [(22, 30), (500, 30), (10000, 32)])
-@pytest.mark.parametrize("tree", [False, True])
+@pytest.mark.parametrize("tree", ["list", "tree_reference", "tree_fast"])
 def test_trace_hit_records(rt, cuda, n, spl, tree):
-    """hitTree / hitable_list::hit: per-ray hit records bit-identical to the oracle."""
+    """hitTree (both traversal modes) / hitable_list::hit: per-ray hit records bit-identical to the oracle."""
     torch = cuda
     nrays = 200_000 if n <= 500 else 60_000
     rays = random_rays(nrays, 1234 + n)
     W = rt.World(n, 1200, 800)
-    O = rt.Octree(W, spl) if tree else None
+    O = rt.Octree(W, spl) if tree != "list" else None
+    if O is not None:
+        O.set_traversal(rt.TRAVERSAL_FAST if tree == "tree_fast" else rt.TRAVERSAL_REFERENCE)
+    tree = tree != "list"
     d_rays = torch.from_numpy(rays).cuda()
     d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
     rt.trace_rays(W, O, d_rays, nrays, d_out)
@@ -87,6 +90,34 @@ def test_render_small_frames(rt, cuda, n, nx, ny, ns, tree, spl):
     assert np.array_equal(bits(got), bits(ref))
     got_st = st.cpu().numpy().view(np.uint32).reshape(-1, 12)
     assert np.array_equal(got_st[:, :6], ref_st[:, :6])
+
+
+def test_fast_traversal_equals_reference_scan_many_rays(rt, cuda):
+    """4M rays (scene-like, grazing, axis-aligned, far origins) through both traversal modes on the GPU: identical records.
+    The reference-scan mode itself is checked against the oracle above."""
+    torch = cuda
+    for n, spl, radius in ((10000, 32, 0.1), (2000, 30, 0.2), (100000, 320, 0.1)):
+        W = rt.World(n, 1200, 800, sphere_radius=radius)
+        O = rt.Octree(W, spl)
+        nrays = 1_000_000
+        rays = random_rays(nrays, 99 + n)
+        # add rays skimming the sphere layer and rays starting on sphere surfaces (secondary-ray like)
+        rng = np.random.default_rng(5)
+        k = nrays // 4
+        rays[:k, 0:3] = rng.uniform([-11, 0.0, -11], [11, 0.25, 11], (k, 3))
+        rays[:k, 3:6] = rng.normal(size=(k, 3)) * np.array([1, 0.05, 1])
+        d_rays = torch.from_numpy(np.ascontiguousarray(rays, np.float32)).cuda()
+        outs = []
+        for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_FAST):
+            O.set_traversal(mode)
+            d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+            rt.trace_rays(W, O, d_rays, nrays, d_out)
+            torch.cuda.synchronize()
+            outs.append(d_out.cpu().numpy().view(np.uint32).reshape(nrays, 8))
+        bad = np.nonzero((outs[0] != outs[1]).any(axis=1))[0]
+        assert bad.size == 0, "n=%d: %d rays differ, first %s" % (n, bad.size, rays[bad[:3]])
+        hits = (outs[0][:, 7].view(np.int32) >= 0).mean()
+        assert hits > 0.2
 
 
 def test_c1_ppm_md5(rt, cuda):
@@ -165,6 +196,10 @@ def test_full_size_properties_c3(rt, cuda):
     fb, st = gpu_render(rt, torch, W, O, nx, ny, ns)
     fb2, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
     assert torch.equal(fb.view(torch.int32), fb2.view(torch.int32))
+    O.set_traversal(rt.TRAVERSAL_REFERENCE)                    # the exact bucket scan gives the same 61 M samples
+    fb3, st3 = gpu_render(rt, torch, W, O, nx, ny, ns)
+    O.set_traversal(rt.TRAVERSAL_FAST)
+    assert torch.equal(fb.view(torch.int32), fb3.view(torch.int32)) and torch.equal(st, st3)
     got = fb.cpu().numpy().reshape(ny, nx, 3)
     # NaN pixels are legitimate reference semantics (dielectric::scatter takes sqrt of a negative number,
     # material.h:95) — they must simply match the oracle bit for bit like everything else.
