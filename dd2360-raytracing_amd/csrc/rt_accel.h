@@ -20,7 +20,7 @@ namespace rt {
 
 struct AccelHost {
     std::vector<float4> large_hot; std::vector<int32_t> large_id;
-    std::vector<int32_t> cs_x, cs_z, id_x, id_z; std::vector<float4> hot_x, hot_z;
+    std::vector<int32_t> cs, id; std::vector<float4> hot;     // x-major copy followed by z-major copy
     std::vector<int32_t> memb_start, memb_cell;
     DevAccel p{};
 };
@@ -56,7 +56,7 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     for (int s = 0; s < n_world; ++s) if (in_tree[s]) radii.push_back(std::sqrt((double)hot_of[s].w));
     DevAccel& p = A.p;
     p = DevAccel{};
-    if (radii.empty()) { p.enabled = 0; A.cs_x.assign(2, 0); A.cs_z.assign(2, 0); return; }
+    if (radii.empty()) { p.enabled = 0; A.cs.assign(4, 0); return; }
     std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
     const double rmed = radii[radii.size() / 2];
     double h = 2.0 * accel_Rp(rmed * rmed);
@@ -86,22 +86,25 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     }
     p.n_large = (int)A.large_id.size();
     const size_t ncell = (size_t)G * G;
-    A.cs_x.assign(ncell + 1, 0); A.cs_z.assign(ncell + 1, 0);
+    std::vector<int32_t> cs_x(ncell + 1, 0), cs_z(ncell + 1, 0);
     for (const Reg& r : regs)
         for (int ix = r.ix0; ix <= r.ix1; ++ix)
-            for (int iz = r.iz0; iz <= r.iz1; ++iz) { A.cs_x[(size_t)ix * G + iz + 1]++; A.cs_z[(size_t)iz * G + ix + 1]++; }
-    for (size_t c = 0; c < ncell; ++c) { A.cs_x[c + 1] += A.cs_x[c]; A.cs_z[c + 1] += A.cs_z[c]; }
-    const size_t total = (size_t)A.cs_x[ncell];
-    A.hot_x.assign(total, make_float4(0, 0, 0, 0)); A.hot_z.assign(total, make_float4(0, 0, 0, 0));
-    A.id_x.assign(total, 0); A.id_z.assign(total, 0);
-    std::vector<int32_t> fx(A.cs_x.begin(), A.cs_x.end() - 1), fz(A.cs_z.begin(), A.cs_z.end() - 1);
+            for (int iz = r.iz0; iz <= r.iz1; ++iz) { cs_x[(size_t)ix * G + iz + 1]++; cs_z[(size_t)iz * G + ix + 1]++; }
+    for (size_t c = 0; c < ncell; ++c) { cs_x[c + 1] += cs_x[c]; cs_z[c + 1] += cs_z[c]; }
+    const size_t total = (size_t)cs_x[ncell];
+    A.hot.assign(2 * total, make_float4(0, 0, 0, 0));
+    A.id.assign(2 * total, 0);
+    std::vector<int32_t> fx(cs_x.begin(), cs_x.end() - 1), fz(cs_z.begin(), cs_z.end() - 1);
     for (const Reg& r : regs)
         for (int ix = r.ix0; ix <= r.ix1; ++ix)
             for (int iz = r.iz0; iz <= r.iz1; ++iz) {
-                const int a = fx[(size_t)ix * G + iz]++, b = fz[(size_t)iz * G + ix]++;
-                A.hot_x[a] = hot_of[r.s]; A.id_x[a] = r.s;
-                A.hot_z[b] = hot_of[r.s]; A.id_z[b] = r.s;
+                const size_t a = (size_t)fx[(size_t)ix * G + iz]++, b = total + (size_t)fz[(size_t)iz * G + ix]++;
+                A.hot[a] = hot_of[r.s]; A.id[a] = r.s;
+                A.hot[b] = hot_of[r.s]; A.id[b] = r.s;
             }
+    A.cs.resize(2 * (ncell + 1));
+    for (size_t c = 0; c <= ncell; ++c) { A.cs[c] = cs_x[c]; A.cs[ncell + 1 + c] = (int32_t)total + cs_z[c]; }
+    p.zoff = (int32_t)(ncell + 1);
     if (regs.empty()) { ylo = 0; yhi = 0; }
     p.ylo = (float)(ylo - 1e-4); p.yhi = (float)(yhi + 1e-4); p.rmax = (float)(rmax + 1e-4);
     p.zone2 = (float)(kZone * kZone);

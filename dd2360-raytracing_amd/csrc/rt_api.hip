@@ -16,6 +16,9 @@ hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part,
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
+#ifdef RT_STATS
+hipError_t read_stats(unsigned long long* out, int reset);
+#endif
 }
 
 using namespace rt;
@@ -32,7 +35,11 @@ struct rt_world {
     std::vector<int32_t> h_ids, h_kind;
     DevScene dev{};
     void* d_list_hot = nullptr; void* d_list_id = nullptr; void* d_geom = nullptr; void* d_mat = nullptr; void* d_kind = nullptr;
+    // work counters of the persistent render kernel: a ring of slots (one per launch, 64 B apart) so that launches
+    // queued on different streams never share one
+    unsigned int* d_queue = nullptr; unsigned launches = 0;
 };
+static const unsigned kQueueSlots = 64, kQueueStride = 16;
 
 struct rt_octree {
     int precision = RT_PRECISION_FP32;
@@ -157,6 +164,8 @@ int rt_world_upload(rt_world* W) {
         (rc = upload(W->h_mat, &W->d_mat)) || (rc = upload(W->h_kind, &W->d_kind))) return rc;
     W->dev.list_hot = (const float4*)W->d_list_hot; W->dev.list_id = (const int32_t*)W->d_list_id;
     W->dev.geom = (const float4*)W->d_geom; W->dev.mat = (const float4*)W->d_mat; W->dev.kind = (const int32_t*)W->d_kind;
+    RT_TRY(hipMalloc((void**)&W->d_queue, kQueueSlots * kQueueStride * sizeof(unsigned int)));
+    RT_TRY(hipMemset(W->d_queue, 0, kQueueSlots * kQueueStride * sizeof(unsigned int)));
     W->uploaded = true;
     return 0;
 }
@@ -164,7 +173,7 @@ int rt_world_upload(rt_world* W) {
 int rt_free_world(rt_world* W) {
     if (!W) return 0;
     int rc = 0;
-    void* bufs[5] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind};
+    void* bufs[6] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue};
     for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
     delete W;
     return rc;
@@ -223,16 +232,13 @@ int rt_octree_upload(rt_octree* O) {
     if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_hot, &O->d_ent_hot)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
     O->dev.nodes4 = (const float4*)O->d_nodes; O->dev.ent_hot = (const float4*)O->d_ent_hot; O->dev.ent_id = (const int32_t*)O->d_ent_id;
     AccelHost& A = O->accel;
-    if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_id, &O->d_acc[1])) || (rc = upload(A.cs_x, &O->d_acc[2])) ||
-        (rc = upload(A.cs_z, &O->d_acc[3])) || (rc = upload(A.hot_x, &O->d_acc[4])) || (rc = upload(A.id_x, &O->d_acc[5])) ||
-        (rc = upload(A.hot_z, &O->d_acc[6])) || (rc = upload(A.id_z, &O->d_acc[7])) || (rc = upload(A.memb_start, &O->d_acc[8])) ||
-        (rc = upload(A.memb_cell, &O->d_acc[9]))) return rc;
+    if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_id, &O->d_acc[1])) || (rc = upload(A.cs, &O->d_acc[2])) ||
+        (rc = upload(A.hot, &O->d_acc[3])) || (rc = upload(A.id, &O->d_acc[4])) || (rc = upload(A.memb_start, &O->d_acc[5])) ||
+        (rc = upload(A.memb_cell, &O->d_acc[6]))) return rc;
     DevAccel& p = A.p;
     p.large_hot = (const float4*)O->d_acc[0]; p.large_id = (const int32_t*)O->d_acc[1];
-    p.cs_x = (const int32_t*)O->d_acc[2]; p.cs_z = (const int32_t*)O->d_acc[3];
-    p.hot_x = (const float4*)O->d_acc[4]; p.id_x = (const int32_t*)O->d_acc[5];
-    p.hot_z = (const float4*)O->d_acc[6]; p.id_z = (const int32_t*)O->d_acc[7];
-    p.memb_start = (const int32_t*)O->d_acc[8]; p.memb_cell = (const int32_t*)O->d_acc[9];
+    p.cs = (const int32_t*)O->d_acc[2]; p.hot = (const float4*)O->d_acc[3]; p.id = (const int32_t*)O->d_acc[4];
+    p.memb_start = (const int32_t*)O->d_acc[5]; p.memb_cell = (const int32_t*)O->d_acc[6];
     O->dev.acc = p;
     O->uploaded = true;
     return 0;
@@ -250,7 +256,7 @@ int rt_octree_accel_info(const rt_octree* O, int* grid_dim, float* cell_size, in
     if (!O) return RT_EINVAL;
     if (grid_dim) *grid_dim = O->accel.p.G;
     if (cell_size) *cell_size = O->accel.p.h;
-    if (grid_entries) *grid_entries = (int)O->accel.id_x.size();
+    if (grid_entries) *grid_entries = (int)(O->accel.id.size() / 2);
     if (large_spheres) *large_spheres = O->accel.p.n_large;
     return 0;
 }
@@ -322,6 +328,9 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
     A.n_local_tiles = (tiles - part.part + part.nparts - 1) / part.nparts;
     A.scene = world->dev;
+    rt_world* wm = const_cast<rt_world*>(world);
+    A.queue = wm->d_queue + (size_t)(wm->launches++ % kQueueSlots) * kQueueStride;
+    RT_TRY(hipMemsetAsync(A.queue, 0, sizeof(unsigned int), (hipStream_t)stream));
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
     return (int)launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream);
@@ -353,6 +362,11 @@ int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float*
     else memset(&T, 0, sizeof(T));
     return (int)launch_trace(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
+
+#ifdef RT_STATS
+// diagnostic build only (librt_amd_stats.so): 16 work counters, see rt_kernels.hip
+int rt_debug_stats(unsigned long long* out16, int reset) { return (int)read_stats(out16, reset); }
+#endif
 
 // ------------------------------------------------------------------------------------------------ output
 static float channel(const void* fb, size_t k, int precision) {

@@ -38,10 +38,13 @@ struct DevScene {
 struct DevAccel {
     const float4* large_hot;   // [n_large] (cx,cy,cz,r^2): tree spheres too big (or too far out) for the grid, always tested
     const int32_t* large_id;   // [n_large]
-    const int32_t* cs_x;       // [G*G+1] cell starts, x-major: cell (ix,iz) at ix*G+iz  -> hot_x / id_x
-    const int32_t* cs_z;       // [G*G+1] cell starts, z-major: cell (ix,iz) at iz*G+ix  -> hot_z / id_z
-    const float4* hot_x; const int32_t* id_x;
-    const float4* hot_z; const int32_t* id_z;
+    // Two copies of the grid so that the cells a ray crosses inside one column of its major axis are contiguous:
+    // x-major (cell (ix,iz) at ix*G+iz) in cs[0 .. G*G], z-major (cell at iz*G+ix) in cs[zoff .. zoff+G*G];
+    // cs values index hot[] / id[] directly (the z-major copy's entries follow the x-major copy's).
+    const int32_t* cs;
+    const float4* hot;         // (cx,cy,cz,r^2)
+    const int32_t* id;         // world-list index
+    int32_t zoff;
     const int32_t* memb_start; // [n+1] per world-list index: range in memb_cell
     const int32_t* memb_cell;  // pre-order node index (DevNode) of each level-3 node whose buckets hold the sphere
     int32_t n_large, G;
@@ -67,6 +70,7 @@ struct RenderArgs {
     int32_t tiles_x, tiles_y;
     int32_t part, nparts;
     int64_t n_local_tiles;
+    unsigned int* queue;                  // work counter of this launch (zeroed on the stream before the launch)
     DevScene scene;
     DevTree tree;
 };

@@ -27,6 +27,21 @@ namespace rt {
 
 #define RT_DEV static __device__ __forceinline__
 
+// Diagnostic build only (-DRT_STATS, tools/stats.sh): per-lane work counters, summed into a global array at kernel end.
+#ifdef RT_STATS
+enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
+       ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_N };
+__device__ unsigned long long g_stats[ST_N];
+struct Stats { unsigned int c[ST_N]; };
+#define STAT(st, k, v) ((st).c[k] += (v))
+#define STAT_ARG , Stats& st
+#define STAT_PASS , st
+#else
+#define STAT(st, k, v) ((void)0)
+#define STAT_ARG
+#define STAT_PASS
+#endif
+
 struct Rng { uint32_t d, v0, v1, v2, v3, v4; };
 
 // curand (XORWOW) + curand_uniform: x * 2^-32 + 2^-33, one rounding per operation
@@ -159,10 +174,12 @@ RT_DEV float sphere_candidate(const RayF& r, float a, const float4 s) {
 // Is the sphere stored in a level-3 node that the reference's traversal visits for this ray?  With no zero direction
 // component a node's slab test passing implies all its ancestors' tests pass (their intervals contain the child's),
 // so the node's own test — the reference's arithmetic — decides.
-RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, int sphere) {
+RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, int sphere STAT_ARG) {
+    STAT(st, ST_ELIG, 1);
     const int mb = T.acc.memb_start[sphere], me = T.acc.memb_start[sphere + 1];
     for (int k = mb; k < me; ++k) {
         const int node = T.acc.memb_cell[k];
+        STAT(st, ST_ELIG_NODES, 1);
         const float4 n0 = s_nodes[node * 3 + 0];
         const float4 n1 = s_nodes[node * 3 + 1];
         if (ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y)) return true;
@@ -170,72 +187,141 @@ RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, int
     return false;
 }
 
-RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int id, float& best_t, int& best, bool& tie) {
+RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int id, float& best_t, int& best, bool& tie STAT_ARG) {
+    STAT(st, ST_OFFERS, 1);
     if (cand < best_t) {
-        if (eligible(T, s_nodes, r, id)) { best_t = cand; best = id; }
+        if (eligible(T, s_nodes, r, id STAT_PASS)) { best_t = cand; best = id; }
     } else if (cand == best_t && id != best && best > 0) {
         tie = true;                      // two different tree spheres at the same float t: visit order decides -> reference scan
     }
 }
 
 // Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
-// clipped to the y-slab that holds them, front to back, stopping once the columns lie beyond the best hit.
-// Returns true when the result must be recomputed by the reference scan (exact tie).
-RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, float a, float& best_t, int& best) {
+// clipped to the y-slab that holds them, front to back, ending at the column that lies beyond the best hit.
+// The walk alternates two phases so that the expensive, rare work is done by many lanes at once:
+//   A  every lane steps through its columns / entries (18-op discriminant only) until it holds a sphere with disc > 0;
+//   B  the lanes holding one take the roots (sqrt, divide) and, if it would win, the reference's slab test (eligible()).
+// Returns true when the result must be recomputed by the reference scan (exact tie between two tree spheres).
+RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, float a, float& best_t, int& best STAT_ARG) {
     const DevAccel& A = T.acc;
     bool tie = false;
     for (int k = 0; k < A.n_large; ++k) {
         const float cand = sphere_candidate(r, a, A.large_hot[k]);
-        offer(T, s_nodes, r, cand, A.large_id[k], best_t, best, tie);
+        offer(T, s_nodes, r, cand, A.large_id[k], best_t, best, tie STAT_PASS);
     }
+    const int32_t* __restrict__ cs = A.cs;
+    const float4* __restrict__ hot = A.hot;
+    const int G = A.G;
+    const float fG = (float)G;
     const float slack = 2e-3f;
     const bool xmajor = fabsf(r.d.x) >= fabsf(r.d.z);
     const float om = xmajor ? r.o.x : r.o.z, on = xmajor ? r.o.z : r.o.x;
     const float dm = xmajor ? r.d.x : r.d.z, dn = xmajor ? r.d.z : r.d.x;
-    const int32_t* __restrict__ cs = xmajor ? A.cs_x : A.cs_z;
-    const float4* __restrict__ hot = xmajor ? A.hot_x : A.hot_z;
-    const int32_t* __restrict__ ids = xmajor ? A.id_x : A.id_z;
-    const int G = A.G;
-    const float fG = (float)G;
+    const int coff = xmajor ? 0 : A.zoff;
+    // everything below is in cell units (cell i spans [i, i+1) along either axis)
+    const float om_c = (om - A.g0) * A.inv_h, on_c = (on - A.g0) * A.inv_h;
+    const float dm_c = dm * A.inv_h;
+    const float s_c = slack * A.inv_h, back_c = (A.rmax + slack) * A.inv_h;
     // where the line crosses the planes y = ylo / y = yhi, measured along the major axis
-    const float rmy = dm / r.d.y;
-    const float mA = om + (A.ylo - r.o.y) * rmy, mB = om + (A.yhi - r.o.y) * rmy;
-    float mlo = fminf(mA, mB) - slack, mhi = fmaxf(mA, mB) + slack;
-    const float back = A.rmax + slack;
-    if (dm > 0.0f) mlo = fmaxf(mlo, om - back); else mhi = fminf(mhi, om + back);     // nothing behind the origin matters
-    const float flo = fminf(fmaxf((mlo - A.g0) * A.inv_h, -1.0f), fG), fhi = fminf(fmaxf((mhi - A.g0) * A.inv_h, -1.0f), fG);
-    int ilo = (int)floorf(flo), ihi = (int)floorf(fhi);
-    if (ihi < 0 || ilo > G - 1 || !(mlo <= mhi)) return tie;
+    const float rmy = dm_c / r.d.y;
+    const float mA = om_c + (A.ylo - r.o.y) * rmy, mB = om_c + (A.yhi - r.o.y) * rmy;
+    float mlo = fminf(mA, mB) - s_c, mhi = fmaxf(mA, mB) + s_c;
+    const bool fwd = dm > 0.0f;
+    if (fwd) mlo = fmaxf(mlo, om_c - back_c); else mhi = fminf(mhi, om_c + back_c);     // nothing behind the origin matters
+    int ilo = (int)floorf(fminf(fmaxf(mlo, -1.0f), fG)), ihi = (int)floorf(fminf(fmaxf(mhi, -1.0f), fG));
+    bool walking = !(ihi < 0 || ilo > G - 1 || !(mlo <= mhi));
     ilo = max(ilo, 0); ihi = min(ihi, G - 1);
-    const int step = dm > 0.0f ? 1 : -1;
-    int i = dm > 0.0f ? ilo : ihi;
-    const int iend = (dm > 0.0f ? ihi : ilo) + step;
+    const int step = fwd ? 1 : -1;
+    int i = fwd ? ilo : ihi;
+    int iend = (fwd ? ihi : ilo) + step;
     const float slope = dn / dm;
-    for (; i != iend; i += step) {
-        const float e0 = A.g0 + (float)i * A.h, e1 = e0 + A.h;
-        if (best >= 0) {                                        // columns entirely beyond the best hit cannot improve it
-            const float pm = om + best_t * dm;
-            const float edge_in = dm > 0.0f ? e0 : e1;
-            if ((edge_in - pm) * (float)step > back) break;
+    // last column worth visiting once a hit at best_t is known: its entry edge is within back_c of the hit point
+    auto clip_to_hit = [&]() {
+        const float pm = fminf(fmaxf(om_c + best_t * dm_c, -4.0f), fG + 4.0f);
+        if (fwd) iend = min(iend, (int)floorf(pm + back_c) + 1);
+        else iend = max(iend, (int)ceilf(pm - back_c - 1.0f) - 1);
+    };
+    if (best >= 0) clip_to_hit();
+    if (fwd ? (i >= iend) : (i <= iend)) walking = false;
+    int e = 0, e_end = 0;
+    float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
+    while (true) {
+        // ---- phase A (wave-uniform loop): lanes without a held sphere take one step per iteration; the wave moves
+        //      on to phase B as soon as the holders are numerous enough to make the expensive code worthwhile
+        while (true) {
+            const bool searching = walking && (p_e < 0);
+            const unsigned long long ms = __ballot(searching), mp = __ballot(p_e >= 0);
+            if (ms == 0ull || __popcll(mp) * 2 >= __popcll(ms)) break;
+            STAT(st, ST_A_ITERS_WAVE, 1);
+            if (searching) {
+                STAT(st, ST_A_LANE_STEPS, 1);
+                if (e < e_end) {
+                    STAT(st, ST_TESTS, 1);
+                    const float4 s = hot[e];
+                    const float ocx = r.o.x - s.x, ocy = r.o.y - s.y, ocz = r.o.z - s.z;
+                    const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
+                    const float disc = b * b - a * c;
+                    if (disc > 0.0f) {
+                        // Cheap pre-filter: approximate roots (v_sqrt / v_rcp, a few ulp) with a margin 400x their error.
+                        // A sphere whose far root is surely <= t_min, or whose near root is surely beyond the best hit,
+                        // is rejected by sphere::hit whatever the exact roots are; the rest goes to phase B.
+                        const float sqa = __builtin_amdgcn_sqrtf(disc), ra = __builtin_amdgcn_rcpf(a);
+                        const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
+                        const bool behind = (sqa - b) * ra + m < 0.001f;
+                        const bool beyond = (-b - sqa) * ra - m > best_t;
+                        if (!behind && !beyond) { p_b = b; p_disc = disc; p_e = e; STAT(st, ST_DISCPOS, 1); }
+                    }
+                    ++e;
+                } else if (i != iend) {
+                    STAT(st, ST_COLS, 1);
+                    // minor-axis extent of the line inside column i: lower edge at i, upper edge at i+1
+                    const float u0 = on_c + ((float)i - om_c) * slope, u1 = u0 + slope;
+                    const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
+                    int k0 = (int)floorf(fminf(fmaxf(lo, -1.0f), fG)), k1 = (int)floorf(fminf(fmaxf(hi, -1.0f), fG));
+                    if (!(k1 < 0 || k0 > G - 1)) {
+                        k0 = max(k0, 0); k1 = min(k1, G - 1);
+                        const int cbase = coff + i * G;
+                        e = cs[cbase + k0];
+                        e_end = cs[cbase + k1 + 1];
+                    }
+                    i += step;
+                } else {
+                    walking = false;
+                }
+            }
         }
-        const float n0 = on + (e0 - om) * slope, n1 = on + (e1 - om) * slope;
-        const float nlo = fminf(n0, n1) - slack, nhi = fmaxf(n0, n1) + slack;
-        const float fk0 = fminf(fmaxf((nlo - A.g0) * A.inv_h, -1.0f), fG), fk1 = fminf(fmaxf((nhi - A.g0) * A.inv_h, -1.0f), fG);
-        int k0 = (int)floorf(fk0), k1 = (int)floorf(fk1);
-        if (k1 < 0 || k0 > G - 1) continue;
-        k0 = max(k0, 0); k1 = min(k1, G - 1);
-        int e = cs[i * G + k0];
-        const int e_end = cs[i * G + k1 + 1];
-        for (; e < e_end; ++e) {
-            const float cand = sphere_candidate(r, a, hot[e]);
-            if (cand <= best_t) offer(T, s_nodes, r, cand, ids[e], best_t, best, tie);
+        if (__ballot(p_e >= 0) == 0ull) break;                 // nobody holds a sphere and nobody is searching
+        STAT(st, ST_B_ROUNDS_WAVE, 1);
+        if (p_e >= 0) {
+        STAT(st, ST_B_LANES, 1);
+        // ---- phase B: roots of the held sphere (sphere.h:24-43), then the offer
+        const int held = p_e;
+        const float sq = sqrtf(p_disc);
+        float cand = __builtin_inff();
+        const float t1 = (-p_b - sq) / a;
+        if (t1 > 0.001f) cand = t1;
+        else {
+            const float t2 = (-p_b + sq) / a;
+            if (t2 > 0.001f) cand = t2;
+        }
+        if (cand <= best_t) {
+            const float before = best_t;
+            offer(T, s_nodes, r, cand, A.id[held], best_t, best, tie STAT_PASS);
+            if (best_t < before) {
+                clip_to_hit();
+                if (fwd ? (i >= iend) : (i <= iend)) { i = iend; }
+            }
+        }
+        p_e = -1;
         }
     }
     return tie;
 }
 
 // hitTree (acceleration_structure.h:319-342): ground sphere first, then the tree.
-RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
+RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best STAT_ARG) {
+    STAT(st, ST_RAYS, live ? 1 : 0);
     if (S.ground_valid) {
         const float4 g = S.list_hot[0];
         int gb = -1;
@@ -249,9 +335,10 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         const bool fast = live && (a >= 9.094947e-13f) && (a <= 1.0995116e12f) && (r.d.x != 0.0f) && (r.d.z != 0.0f)
                           && (fabsf(r.d.y) >= 9.094947e-13f) && (zx * zx + zy * zy + zz * zz <= T.acc.zone2);
         slow = live && !fast;
+        STAT(st, ST_FAST, fast ? 1 : 0); STAT(st, ST_SLOW, slow ? 1 : 0);
         if (fast) {
             const float g_t = closest; const int g_id = best;
-            if (tree_fast(T, s_nodes, r, a, closest, best)) { closest = g_t; best = g_id; slow = true; }
+            if (tree_fast(T, s_nodes, r, a, closest, best STAT_PASS)) { closest = g_t; best = g_id; slow = true; STAT(st, ST_TIE, 1); }
         }
     }
     if (__ballot(slow) != 0ull) tree_scan(T, s_nodes, r, a, slow, closest, best);
@@ -382,6 +469,11 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
 }
 
 // MODE 0: render (ns samples, /ns, sqrt).  MODE 1: render_progressive (one sample, accumulate).
+//
+// Persistent waves: the grid is sized to what the chip holds at once.  Pixel slots are numbered tile-major
+// (slot = local_tile*64 + ly*8 + lx, the 8x8 block shape of the reference); every lane starts on slot
+// (wave*64 + lane) and, when its pixel is finished, pulls the next unclaimed slot from a global counter, so no lane
+// waits for the slowest pixel of "its" tile.  Which lane renders a pixel does not affect the pixel (the RNG is per pixel).
 template <bool TREE, int MODE>
 __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
@@ -391,31 +483,66 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (local_tile >= A.n_local_tiles) return;
-    const long long tile = A.part + local_tile * A.nparts;
-    const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
-    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
-    const bool inside = (i < A.max_x) && (j < A.max_y);
-    const long long idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + lane;
-
-    Rng s = {0, 0, 0, 0, 0, 0};
-    if (inside) {
-        const rt_rand_state* st = A.rand_state + idx;
-        s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
-    }
+    const long long n_slots = A.n_local_tiles * 64;
+    const long long first_free = (long long)gridDim.x * 256;       // slots below this are handed out statically
     const int ns = (MODE == 0) ? A.ns : 1;
+
+    long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    int i = 0, j = 0; long long idx = 0;
+    Rng s = {0, 0, 0, 0, 0, 0};
     V3 col = {0.0f, 0.0f, 0.0f};
     V3 att = {1.0f, 1.0f, 1.0f};
     RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
     int sample = 0, depth = 0;
-    bool live = inside && ns > 0;
-    if (live) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+    bool live = false;
 
+    // claim `slot` (skipping slots that fall outside the frame in edge tiles) and set the lane up for that pixel
+    auto begin_pixel = [&]() {
+        live = false;
+        while (slot < n_slots) {
+            const long long local_tile = slot >> 6;
+            const int l = (int)(slot & 63);
+            const long long tile = A.part + local_tile * A.nparts;
+            const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+            i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
+            if (i < A.max_x && j < A.max_y) {
+                idx = (A.nparts == 1) ? (long long)j * A.max_x + i : slot;
+                live = true;
+                break;
+            }
+            slot = first_free + (long long)atomicAdd(A.queue, 1u);
+        }
+        if (live) {
+            const rt_rand_state* st = A.rand_state + idx;
+            s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
+            col = {0.0f, 0.0f, 0.0f}; att = {1.0f, 1.0f, 1.0f}; sample = 0; depth = 0;
+            r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+        }
+    };
+    // rand_state[pixel_index] = local_rand_state; fb[pixel_index] = ...  (main.cu:110-115 / :133-141)
+    auto end_pixel = [&]() {
+        rt_rand_state* st_out = A.rand_state + idx;
+        st_out->d = s.d; st_out->v[0] = s.v0; st_out->v[1] = s.v1; st_out->v[2] = s.v2; st_out->v[3] = s.v3; st_out->v[4] = s.v4;
+        float* fb = (float*)A.fb + idx * 3;
+        if (MODE == 0) {
+            const float k = (float)(1.0 / (double)(float)A.ns);          // vec3::operator/=(real_t): 1.0/t in double (vec3.h:137)
+            col.x *= k; col.y *= k; col.z *= k;
+            fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
+        } else {
+            if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
+            else { fb[0] += col.x; fb[1] += col.y; fb[2] += col.z; }
+        }
+    };
+    if (ns > 0) begin_pixel();
+
+#ifdef RT_STATS
+    Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
+#endif
     while (__ballot(live) != 0ull) {
+        STAT(st, ST_LOOP_ITERS_WAVE, 1);
         const float a = dot3(r.d, r.d);
         float closest = FLT_MAX; int best = -1;
-        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best);
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
         else closest_list(A.scene, r, a, closest, best);
         if (live) {
             bool done;                                     // this sample's path has ended
@@ -431,23 +558,22 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
             if (done) {
                 ++sample; depth = 0; att = {1.0f, 1.0f, 1.0f};
                 if (sample < ns) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
-                else live = false;
+                else {
+                    end_pixel();
+                    slot = first_free + (long long)atomicAdd(A.queue, 1u);
+                    begin_pixel();
+                }
             }
         }
     }
 
-    if (!inside) return;
-    rt_rand_state* st = A.rand_state + idx;
-    st->d = s.d; st->v[0] = s.v0; st->v[1] = s.v1; st->v[2] = s.v2; st->v[3] = s.v3; st->v[4] = s.v4;
-    float* fb = (float*)A.fb + idx * 3;
-    if (MODE == 0) {
-        const float k = (float)(1.0 / (double)(float)A.ns);          // vec3::operator/=(real_t): 1.0/t in double (vec3.h:137)
-        col.x *= k; col.y *= k; col.z *= k;
-        fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
-    } else {
-        if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
-        else { fb[0] += col.x; fb[1] += col.y; fb[2] += col.z; }
+#ifdef RT_STATS
+    for (int q = 0; q < ST_N; ++q) {
+        const bool wave_level = (q == ST_A_ITERS_WAVE || q == ST_B_ROUNDS_WAVE || q == ST_LOOP_ITERS_WAVE);
+        if (st.c[q] && (!wave_level || lane == 0)) atomicAdd(&g_stats[q], (unsigned long long)st.c[q]);
     }
+    if (lane == 0) atomicAdd(&g_stats[ST_SAMPLES], 1ull);
+#endif
 }
 
 // hitTree / hitable_list::hit for a batch of rays (one lane per ray)
@@ -465,7 +591,10 @@ __global__ __launch_bounds__(256) void k_trace(DevScene S, DevTree T, const floa
     if (live) { const float* p = rays + gid * 6; r.o = {p[0], p[1], p[2]}; r.d = {p[3], p[4], p[5]}; }
     const float a = dot3(r.d, r.d);
     float closest = FLT_MAX; int best = -1;
-    if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best);
+#ifdef RT_STATS
+    Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
+#endif
+    if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best STAT_PASS);
     else closest_list(S, r, a, closest, best);
     if (!live) return;
     rt_hit_record h;
@@ -503,10 +632,24 @@ hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part,
     return hipGetLastError();
 }
 
+// blocks the chip holds at once for one render kernel variant (occupancy query, cached); the persistent grid is never
+// larger than that, and never larger than the work
+template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024u;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    return (unsigned)(cus * per_cu);
+}
+
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((A.n_local_tiles + 3) / 4);
+    const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
     const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
+    unsigned cap;
+    if (tree) cap = mode == 0 ? resident_blocks(k_render<true, 0>, lds) : resident_blocks(k_render<true, 1>, lds);
+    else cap = mode == 0 ? resident_blocks(k_render<false, 0>, lds) : resident_blocks(k_render<false, 1>, lds);
+    const unsigned blocks = need < cap ? need : cap;
     if (tree) {
         if (mode == 0) hipLaunchKernelGGL((k_render<true, 0>), dim3(blocks), dim3(256), lds, st, A);
         else hipLaunchKernelGGL((k_render<true, 1>), dim3(blocks), dim3(256), lds, st, A);
@@ -534,5 +677,14 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, st, full, parts, max_x, max_y, tiles_x, nparts, per_part, tiles);
     return hipGetLastError();
 }
+
+#ifdef RT_STATS
+hipError_t read_stats(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * ST_N);
+    if (e != hipSuccess) return e;
+    if (reset) { unsigned long long z[ST_N] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)); }
+    return e;
+}
+#endif
 
 } // namespace rt

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Work counters of the render kernel (diagnostic build librt_amd_stats.so, -DRT_STATS).  GPU box only."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
+import torch
+import rt_amd as rt
+rt.LIB_PATH = os.path.join(ROOT, "dd2360-raytracing_amd", "librt_amd_stats.so")
+L = rt.lib()
+L.rt_debug_stats.restype = C.c_int
+L.rt_debug_stats.argtypes = [C.c_void_p, C.c_int]
+names = ["rays", "fast", "slow", "tie", "cols", "tests", "discpos", "offers", "elig", "elig_nodes", "A_iters_wave", "B_rounds_wave",
+         "loop_iters_wave", "A_lane_steps", "B_lanes", "waves"]
+n, nx, ny, ns, spl = (int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (10000, 1200, 800, 8, 32)))
+W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload()
+st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
+buf = (C.c_ulonglong * 16)()
+rt.render_init(nx, ny, st); torch.cuda.synchronize()
+L.rt_debug_stats(buf, 1)
+rt.render(fb, nx, ny, ns, W, st, O); torch.cuda.synchronize()
+L.rt_debug_stats(buf, 1)
+v = dict(zip(names, list(buf)))
+rays = max(1, v["rays"]); samples = nx * ny * ns; waves = max(1, v["waves"])
+print("accel", O.accel_info())
+print("samples %d rays/sample %.3f fast %.4f slow %.5f ties %d" % (samples, rays / samples, v["fast"] / rays, v["slow"] / rays, v["tie"]))
+for k in ("cols", "tests", "discpos", "offers", "elig", "elig_nodes", "A_lane_steps", "B_lanes"):
+    print("  %-14s %8.3f per ray" % (k, v[k] / rays))
+print("per wave: loop iters %.1f, A iters %.1f (%.1f per loop iter), B rounds %.1f (%.2f per loop iter)" %
+      (v["loop_iters_wave"] / waves, v["A_iters_wave"] / waves, v["A_iters_wave"] / max(1, v["loop_iters_wave"]),
+       v["B_rounds_wave"] / waves, v["B_rounds_wave"] / max(1, v["loop_iters_wave"])))
+print("lane utilisation: phase A %.3f, phase B %.3f, rays per loop iter %.2f of 64" %
+      (v["A_lane_steps"] / max(1, 64 * v["A_iters_wave"]), v["B_lanes"] / max(1, 64 * v["B_rounds_wave"]), rays / max(1, v["loop_iters_wave"])))
