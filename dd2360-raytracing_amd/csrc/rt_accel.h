@@ -20,7 +20,7 @@ namespace rt {
 
 struct AccelHost {
     std::vector<float4> large_hot; std::vector<int32_t> large_id;
-    std::vector<int32_t> cs, id; std::vector<float4> hot;     // x-major copy followed by z-major copy
+    std::vector<int32_t> cs, id, node1; std::vector<float4> hot;     // x-major copy followed by z-major copy
     std::vector<int32_t> memb_start, memb_cell;
     DevAccel p{};
 };
@@ -94,13 +94,15 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     const size_t total = (size_t)cs_x[ncell];
     A.hot.assign(2 * total, make_float4(0, 0, 0, 0));
     A.id.assign(2 * total, 0);
+    A.node1.assign(2 * total, -1);
     std::vector<int32_t> fx(cs_x.begin(), cs_x.end() - 1), fz(cs_z.begin(), cs_z.end() - 1);
     for (const Reg& r : regs)
         for (int ix = r.ix0; ix <= r.ix1; ++ix)
             for (int iz = r.iz0; iz <= r.iz1; ++iz) {
                 const size_t a = (size_t)fx[(size_t)ix * G + iz]++, b = total + (size_t)fz[(size_t)iz * G + ix]++;
-                A.hot[a] = hot_of[r.s]; A.id[a] = r.s;
-                A.hot[b] = hot_of[r.s]; A.id[b] = r.s;
+                const int32_t single = (A.memb_start[(size_t)r.s + 1] - A.memb_start[r.s] == 1) ? A.memb_cell[A.memb_start[r.s]] : -1;
+                A.hot[a] = hot_of[r.s]; A.id[a] = r.s; A.node1[a] = single;
+                A.hot[b] = hot_of[r.s]; A.id[b] = r.s; A.node1[b] = single;
             }
     A.cs.resize(2 * (ncell + 1));
     for (size_t c = 0; c <= ncell; ++c) { A.cs[c] = cs_x[c]; A.cs[ncell + 1 + c] = (int32_t)total + cs_z[c]; }

@@ -14,6 +14,7 @@
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
+hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, hipStream_t st);
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
 #ifdef RT_STATS
@@ -38,6 +39,8 @@ struct rt_world {
     // work counters of the persistent render kernel: a ring of slots (one per launch, 64 B apart) so that launches
     // queued on different streams never share one
     unsigned int* d_queue = nullptr; unsigned launches = 0;
+    // scheduling workspace of rt_render (tile costs and hand-out order), grown on demand
+    int* d_cost = nullptr; unsigned int* d_order = nullptr; int64_t sched_tiles = 0;
 };
 static const unsigned kQueueSlots = 64, kQueueStride = 16;
 
@@ -50,7 +53,7 @@ struct rt_octree {
     int traversal = RT_TRAVERSAL_FAST;
     DevTree dev{};
     void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
-    void* d_acc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* d_acc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [7] = node1
 };
 
 template <class T> static int upload(const std::vector<T>& v, void** d) {
@@ -173,7 +176,7 @@ int rt_world_upload(rt_world* W) {
 int rt_free_world(rt_world* W) {
     if (!W) return 0;
     int rc = 0;
-    void* bufs[6] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue};
+    void* bufs[8] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue, W->d_cost, W->d_order};
     for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
     delete W;
     return rc;
@@ -234,11 +237,11 @@ int rt_octree_upload(rt_octree* O) {
     AccelHost& A = O->accel;
     if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_id, &O->d_acc[1])) || (rc = upload(A.cs, &O->d_acc[2])) ||
         (rc = upload(A.hot, &O->d_acc[3])) || (rc = upload(A.id, &O->d_acc[4])) || (rc = upload(A.memb_start, &O->d_acc[5])) ||
-        (rc = upload(A.memb_cell, &O->d_acc[6]))) return rc;
+        (rc = upload(A.memb_cell, &O->d_acc[6])) || (rc = upload(A.node1, &O->d_acc[7]))) return rc;
     DevAccel& p = A.p;
     p.large_hot = (const float4*)O->d_acc[0]; p.large_id = (const int32_t*)O->d_acc[1];
     p.cs = (const int32_t*)O->d_acc[2]; p.hot = (const float4*)O->d_acc[3]; p.id = (const int32_t*)O->d_acc[4];
-    p.memb_start = (const int32_t*)O->d_acc[5]; p.memb_cell = (const int32_t*)O->d_acc[6];
+    p.memb_start = (const int32_t*)O->d_acc[5]; p.memb_cell = (const int32_t*)O->d_acc[6]; p.node1 = (const int32_t*)O->d_acc[7];
     O->dev.acc = p;
     O->uploaded = true;
     return 0;
@@ -333,6 +336,21 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     RT_TRY(hipMemsetAsync(A.queue, 0, sizeof(unsigned int), (hipStream_t)stream));
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
+    A.order = nullptr;
+    if (mode == 0 && ns >= 4) {
+        // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame:
+        // call rt_render once before capturing it into a hipGraph.
+        if (wm->sched_tiles < A.n_local_tiles) {
+            if (wm->d_cost) { RT_TRY(hipFree(wm->d_cost)); wm->d_cost = nullptr; }
+            if (wm->d_order) { RT_TRY(hipFree(wm->d_order)); wm->d_order = nullptr; }
+            wm->sched_tiles = 0;
+            RT_TRY(hipMalloc((void**)&wm->d_cost, sizeof(int) * (size_t)A.n_local_tiles));
+            RT_TRY(hipMalloc((void**)&wm->d_order, sizeof(unsigned int) * (size_t)A.n_local_tiles));
+            wm->sched_tiles = A.n_local_tiles;
+        }
+        RT_TRY(launch_tile_order(A, d_octree != nullptr, wm->d_cost, wm->d_order, (hipStream_t)stream));
+        A.order = wm->d_order;
+    }
     return (int)launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream);
 }
 

@@ -44,6 +44,7 @@ struct DevAccel {
     const int32_t* cs;
     const float4* hot;         // (cx,cy,cz,r^2)
     const int32_t* id;         // world-list index
+    const int32_t* node1;      // per entry: the single level-3 node (pre-order index) that stores the sphere, or -1 if several do
     int32_t zoff;
     const int32_t* memb_start; // [n+1] per world-list index: range in memb_cell
     const int32_t* memb_cell;  // pre-order node index (DevNode) of each level-3 node whose buckets hold the sphere
@@ -71,6 +72,7 @@ struct RenderArgs {
     int32_t part, nparts;
     int64_t n_local_tiles;
     unsigned int* queue;                  // work counter of this launch (zeroed on the stream before the launch)
+    const unsigned int* order;            // hand-out order of the local tiles (most expensive first), or NULL = identity
     DevScene scene;
     DevTree tree;
 };

@@ -27,12 +27,27 @@ namespace rt {
 
 #define RT_DEV static __device__ __forceinline__
 
+// minimum waves per SIMD the render kernel is compiled for (register budget 512/RT_RENDER_WAVES VGPRs per lane)
+#ifndef RT_RENDER_WAVES
+#define RT_RENDER_WAVES 4
+#endif
+// grid entries tested per walk step (loads in flight together)
+#ifndef RT_BATCH
+#define RT_BATCH 8
+#endif
+// phase B starts when holders * RT_VOTE_NUM >= searchers (or nobody searches)
+#ifndef RT_VOTE_NUM
+#define RT_VOTE_NUM 2
+#endif
+
 // Diagnostic build only (-DRT_STATS, tools/stats.sh): per-lane work counters, summed into a global array at kernel end.
 #ifdef RT_STATS
 enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
-       ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_N };
+       ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_LIVE_GE56, ST_LIVE_32, ST_LIVE_8, ST_LIVE_LT8, ST_SWITCHES,
+       ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME, ST_N };
+#define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
-struct Stats { unsigned int c[ST_N]; };
+struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
 #define STAT(st, k, v) ((st).c[k] += (v))
 #define STAT_ARG , Stats& st
 #define STAT_PASS , st
@@ -187,10 +202,20 @@ RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, int
     return false;
 }
 
-RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int id, float& best_t, int& best, bool& tie STAT_ARG) {
+// node1 >= 0: the sphere is stored in exactly that level-3 node (no membership lookup needed); -1: look the list up
+RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int id, int node1, float& best_t, int& best, bool& tie STAT_ARG) {
     STAT(st, ST_OFFERS, 1);
     if (cand < best_t) {
-        if (eligible(T, s_nodes, r, id STAT_PASS)) { best_t = cand; best = id; }
+        bool ok;
+        if (node1 >= 0) {
+            STAT(st, ST_ELIG, 1); STAT(st, ST_ELIG_NODES, 1);
+            const float4 n0 = s_nodes[node1 * 3 + 0];
+            const float4 n1 = s_nodes[node1 * 3 + 1];
+            ok = ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+        } else {
+            ok = eligible(T, s_nodes, r, id STAT_PASS);
+        }
+        if (ok) { best_t = cand; best = id; }
     } else if (cand == best_t && id != best && best > 0) {
         tie = true;                      // two different tree spheres at the same float t: visit order decides -> reference scan
     }
@@ -207,7 +232,7 @@ RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, fl
     bool tie = false;
     for (int k = 0; k < A.n_large; ++k) {
         const float cand = sphere_candidate(r, a, A.large_hot[k]);
-        offer(T, s_nodes, r, cand, A.large_id[k], best_t, best, tie STAT_PASS);
+        offer(T, s_nodes, r, cand, A.large_id[k], -1, best_t, best, tie STAT_PASS);
     }
     const int32_t* __restrict__ cs = A.cs;
     const float4* __restrict__ hot = A.hot;
@@ -244,49 +269,81 @@ RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, fl
     if (best >= 0) clip_to_hit();
     if (fwd ? (i >= iend) : (i <= iend)) walking = false;
     int e = 0, e_end = 0;
+    int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
     float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
+    int p_id = 0, p_node = -1;
+    // A thin wave has nothing to hide an L2 round trip behind (~1000 cycles per dependent load), and the frame cannot end
+    // before its longest pixel chain does — so the walk keeps several loads in flight: the cell range of the next
+    // column is fetched while the current column's entries are tested, and entries are tested four at a time.
+    auto prefetch_col = [&]() {
+        // minor-axis extent of the line inside column i: lower edge at i, upper edge at i+1
+        const float u0 = on_c + ((float)i - om_c) * slope, u1 = u0 + slope;
+        const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
+        int k0 = (int)floorf(fminf(fmaxf(lo, -1.0f), fG)), k1 = (int)floorf(fminf(fmaxf(hi, -1.0f), fG));
+        ne = 0; ne_end = 0;
+        if (!(k1 < 0 || k0 > G - 1)) {
+            k0 = max(k0, 0); k1 = min(k1, G - 1);
+            const int cbase = coff + i * G;
+            ne = cs[cbase + k0];
+            ne_end = cs[cbase + k1 + 1];
+        }
+    };
+    if (walking) prefetch_col();
     while (true) {
         // ---- phase A (wave-uniform loop): lanes without a held sphere take one step per iteration; the wave moves
         //      on to phase B as soon as the holders are numerous enough to make the expensive code worthwhile
         while (true) {
             const bool searching = walking && (p_e < 0);
             const unsigned long long ms = __ballot(searching), mp = __ballot(p_e >= 0);
-            if (ms == 0ull || __popcll(mp) * 2 >= __popcll(ms)) break;
+            if (ms == 0ull || __popcll(mp) * RT_VOTE_NUM >= __popcll(ms)) break;
             STAT(st, ST_A_ITERS_WAVE, 1);
             if (searching) {
                 STAT(st, ST_A_LANE_STEPS, 1);
-                if (e < e_end) {
-                    STAT(st, ST_TESTS, 1);
-                    const float4 s = hot[e];
-                    const float ocx = r.o.x - s.x, ocy = r.o.y - s.y, ocz = r.o.z - s.z;
-                    const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
-                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
-                    const float disc = b * b - a * c;
-                    if (disc > 0.0f) {
-                        // Cheap pre-filter: approximate roots (v_sqrt / v_rcp, a few ulp) with a margin 400x their error.
-                        // A sphere whose far root is surely <= t_min, or whose near root is surely beyond the best hit,
-                        // is rejected by sphere::hit whatever the exact roots are; the rest goes to phase B.
-                        const float sqa = __builtin_amdgcn_sqrtf(disc), ra = __builtin_amdgcn_rcpf(a);
-                        const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
-                        const bool behind = (sqa - b) * ra + m < 0.001f;
-                        const bool beyond = (-b - sqa) * ra - m > best_t;
-                        if (!behind && !beyond) { p_b = b; p_disc = disc; p_e = e; STAT(st, ST_DISCPOS, 1); }
-                    }
-                    ++e;
-                } else if (i != iend) {
+                if (e >= e_end && i != iend) {                 // enter the next column (its range was fetched a step ago)
                     STAT(st, ST_COLS, 1);
-                    // minor-axis extent of the line inside column i: lower edge at i, upper edge at i+1
-                    const float u0 = on_c + ((float)i - om_c) * slope, u1 = u0 + slope;
-                    const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-                    int k0 = (int)floorf(fminf(fmaxf(lo, -1.0f), fG)), k1 = (int)floorf(fminf(fmaxf(hi, -1.0f), fG));
-                    if (!(k1 < 0 || k0 > G - 1)) {
-                        k0 = max(k0, 0); k1 = min(k1, G - 1);
-                        const int cbase = coff + i * G;
-                        e = cs[cbase + k0];
-                        e_end = cs[cbase + k1 + 1];
-                    }
+                    e = ne; e_end = ne_end;
                     i += step;
-                } else {
+                    if (i != iend) prefetch_col();
+                }
+                if (e < e_end) {
+                    const int last = e_end - 1;
+                    int take = min(RT_BATCH, e_end - e);
+                    STAT(st, ST_TESTS, take);
+                    float4 s4[RT_BATCH];
+#pragma unroll
+                    for (int k = 0; k < RT_BATCH; ++k) s4[k] = hot[min(e + k, last)];
+                    float bb[RT_BATCH], dd[RT_BATCH];
+                    float dmax = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < RT_BATCH; ++k) {
+                        const float ocx = r.o.x - s4[k].x, ocy = r.o.y - s4[k].y, ocz = r.o.z - s4[k].z;
+                        bb[k] = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+                        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[k].w;
+                        dd[k] = bb[k] * bb[k] - a * c;
+                        dmax = fmaxf(dmax, k < take ? dd[k] : 0.0f);
+                    }
+                    if (dmax > 0.0f) {
+                        const float ra = __builtin_amdgcn_rcpf(a);
+#pragma unroll
+                        for (int k = 0; k < RT_BATCH; ++k) {
+                            if (k < take && dd[k] > 0.0f) {
+                                // Cheap pre-filter: approximate roots (v_sqrt / v_rcp, a few ulp) with a margin 400x their error.
+                                // A sphere whose far root is surely <= t_min, or whose near root is surely beyond the best hit,
+                                // is rejected by sphere::hit whatever the exact roots are; the rest goes to phase B.
+                                const float sqa = __builtin_amdgcn_sqrtf(dd[k]);
+                                const float m = 1e-4f * ((fabsf(bb[k]) + sqa) * ra) + 1e-6f;
+                                const bool behind = (sqa - bb[k]) * ra + m < 0.001f;
+                                const bool beyond = (-bb[k] - sqa) * ra - m > best_t;
+                                if (!behind && !beyond) {
+                                    p_b = bb[k]; p_disc = dd[k]; p_e = e + k; take = k + 1;      // entries after k are re-tested later
+                                    p_id = A.id[e + k]; p_node = A.node1[e + k];                  // in flight until phase B
+                                    STAT(st, ST_DISCPOS, 1);
+                                }
+                            }
+                        }
+                    }
+                    e += take;
+                } else if (i == iend) {
                     walking = false;
                 }
             }
@@ -296,7 +353,6 @@ RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, fl
         if (p_e >= 0) {
         STAT(st, ST_B_LANES, 1);
         // ---- phase B: roots of the held sphere (sphere.h:24-43), then the offer
-        const int held = p_e;
         const float sq = sqrtf(p_disc);
         float cand = __builtin_inff();
         const float t1 = (-p_b - sq) / a;
@@ -307,7 +363,7 @@ RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, fl
         }
         if (cand <= best_t) {
             const float before = best_t;
-            offer(T, s_nodes, r, cand, A.id[held], best_t, best, tie STAT_PASS);
+            offer(T, s_nodes, r, cand, p_id, p_node, best_t, best, tie STAT_PASS);
             if (best_t < before) {
                 clip_to_hit();
                 if (fwd ? (i >= iend) : (i <= iend)) { i = iend; }
@@ -328,6 +384,9 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
         if (gb == 0) best = 0;
     }
+#ifdef RT_STATS
+    const unsigned long long tG = TICK(); st.cyc[4] += tG;      // (entry stamp is subtracted by the caller's tC0)
+#endif
     bool slow = live;
     if (T.acc.enabled) {
         // preconditions of the exactness argument; any NaN/inf makes a comparison false and sends the ray to the scan
@@ -341,7 +400,13 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             if (tree_fast(T, s_nodes, r, a, closest, best STAT_PASS)) { closest = g_t; best = g_id; slow = true; STAT(st, ST_TIE, 1); }
         }
     }
+#ifdef RT_STATS
+    const unsigned long long tS0 = TICK(); st.cyc[1] += tS0 - tG;     // fast path (large spheres + setup + walk), wave time
+#endif
     if (__ballot(slow) != 0ull) tree_scan(T, s_nodes, r, a, slow, closest, best);
+#ifdef RT_STATS
+    st.cyc[3] += TICK() - tS0;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- sampling
@@ -475,7 +540,7 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
 // (wave*64 + lane) and, when its pixel is finished, pulls the next unclaimed slot from a global counter, so no lane
 // waits for the slowest pixel of "its" tile.  Which lane renders a pixel does not affect the pixel (the RNG is per pixel).
 template <bool TREE, int MODE>
-__global__ __launch_bounds__(256) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
     if (TREE) {
         const int n4 = A.tree.n_nodes * 3;
@@ -495,18 +560,22 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
     RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
     int sample = 0, depth = 0;
     bool live = false;
+#ifdef RT_STATS
+    unsigned int pix_iters = 0, pix_steps = 0, steps_mark = 0;
+#endif
 
     // claim `slot` (skipping slots that fall outside the frame in edge tiles) and set the lane up for that pixel
     auto begin_pixel = [&]() {
         live = false;
         while (slot < n_slots) {
-            const long long local_tile = slot >> 6;
+            const long long rank = slot >> 6;                                  // position in the hand-out order
+            const long long local_tile = A.order ? (long long)A.order[rank] : rank;
             const int l = (int)(slot & 63);
             const long long tile = A.part + local_tile * A.nparts;
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
             if (i < A.max_x && j < A.max_y) {
-                idx = (A.nparts == 1) ? (long long)j * A.max_x + i : slot;
+                idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l;
                 live = true;
                 break;
             }
@@ -528,22 +597,37 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
             const float k = (float)(1.0 / (double)(float)A.ns);          // vec3::operator/=(real_t): 1.0/t in double (vec3.h:137)
             col.x *= k; col.y *= k; col.z *= k;
             fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
+#ifdef RT_STATS
+            fb[0] = (float)pix_iters; fb[1] = (float)pix_steps;      // diagnostic build: chain length instead of colour
+#endif
         } else {
             if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
             else { fb[0] += col.x; fb[1] += col.y; fb[2] += col.z; }
         }
     };
-    if (ns > 0) begin_pixel();
-
 #ifdef RT_STATS
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
+    for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
+    const unsigned long long tK0 = TICK(), rK0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (ns > 0) begin_pixel();
+
     while (__ballot(live) != 0ull) {
         STAT(st, ST_LOOP_ITERS_WAVE, 1);
+#ifdef RT_STATS
+        { const int nl = __popcll(__ballot(live)); STAT(st, nl >= 56 ? ST_LIVE_GE56 : nl >= 32 ? ST_LIVE_32 : nl >= 8 ? ST_LIVE_8 : ST_LIVE_LT8, 1); }
+#endif
         const float a = dot3(r.d, r.d);
         float closest = FLT_MAX; int best = -1;
+#ifdef RT_STATS
+        const unsigned long long tC0 = TICK();
+#endif
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
         else closest_list(A.scene, r, a, closest, best);
+#ifdef RT_STATS
+        const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0;
+        if (live) { ++pix_iters; }
+#endif
         if (live) {
             bool done;                                     // this sample's path has ended
             if (best >= 0) {
@@ -559,7 +643,14 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
                 ++sample; depth = 0; att = {1.0f, 1.0f, 1.0f};
                 if (sample < ns) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
                 else {
+#ifdef RT_STATS
+                    pix_steps = st.c[ST_A_LANE_STEPS] - steps_mark; steps_mark = st.c[ST_A_LANE_STEPS];
+#endif
                     end_pixel();
+#ifdef RT_STATS
+                    pix_iters = 0;
+#endif
+                    STAT(st, ST_SWITCHES, 1);
                     slot = first_free + (long long)atomicAdd(A.queue, 1u);
                     begin_pixel();
                 }
@@ -569,11 +660,99 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
 
 #ifdef RT_STATS
     for (int q = 0; q < ST_N; ++q) {
-        const bool wave_level = (q == ST_A_ITERS_WAVE || q == ST_B_ROUNDS_WAVE || q == ST_LOOP_ITERS_WAVE);
-        if (st.c[q] && (!wave_level || lane == 0)) atomicAdd(&g_stats[q], (unsigned long long)st.c[q]);
+        const bool wave_level = (q == ST_LOOP_ITERS_WAVE || (q >= ST_LIVE_GE56 && q <= ST_LIVE_LT8));
+        const bool lane_max = (q == ST_A_ITERS_WAVE || q == ST_B_ROUNDS_WAVE);       // single-wave probes: max over lanes = wave count
+        if (lane_max) { int m = (int)st.c[q]; for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off)); if (lane == 0) atomicAdd(&g_stats[q], (unsigned long long)m); }
+        else if (st.c[q] && (!wave_level || lane == 0)) atomicAdd(&g_stats[q], (unsigned long long)st.c[q]);
     }
-    if (lane == 0) atomicAdd(&g_stats[ST_SAMPLES], 1ull);
+    if (lane == 0) {
+        atomicAdd(&g_stats[ST_SAMPLES], 1ull);
+        const unsigned long long tot = TICK() - tK0;
+        atomicAdd(&g_stats[ST_CYC_TOTAL], tot);
+        atomicAdd(&g_stats[ST_CYC_CLOSEST], st.cyc[0]); atomicAdd(&g_stats[ST_CYC_WALK_A], st.cyc[1]); atomicAdd(&g_stats[ST_CYC_WALK_B], st.cyc[4] - st.cyc[2]);
+        atomicAdd(&g_stats[ST_CYC_SCAN], st.cyc[3]); atomicAdd(&g_stats[ST_CYC_SHADE], tot - st.cyc[0]);
+        atomicAdd(&g_stats[ST_REALTIME], __builtin_amdgcn_s_memrealtime() - rK0);
+    }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------- scheduling
+// Longest-processing-time-first hand-out order for the persistent render kernel.  A pixel is a strictly serial chain
+// (ns samples x bounces on one RNG stream); with only a few pixels per resident lane, a long chain picked up late keeps
+// a nearly empty wave running.  k_tile_cost shoots one deterministic centre ray per pixel (no RNG is touched) and
+// weighs what it hits (glass paths are long, sky paths are one ray); k_tile_order sorts the tiles into 8 cost classes,
+// most expensive first, stably.  The order changes only WHICH lane renders a pixel, never the pixel.
+template <bool TREE>
+__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost) {
+    extern __shared__ float4 s_nodes[];
+    if (TREE) {
+        const int n4 = A.tree.n_nodes * 3;
+        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (local_tile >= A.n_local_tiles) return;
+    const long long tile = A.part + local_tile * A.nparts;
+    const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+    const bool inside = (i < A.max_x) && (j < A.max_y);
+    const rt_camera& c = A.scene.cam;
+    const float u = ((float)i + 0.5f) / (float)A.max_x, v = ((float)j + 0.5f) / (float)A.max_y;
+    RayF r;
+    r.o = {c.origin[0], c.origin[1], c.origin[2]};
+    r.d.x = c.lower_left_corner[0] + u * c.horizontal[0] + v * c.vertical[0] - c.origin[0];
+    r.d.y = c.lower_left_corner[1] + u * c.horizontal[1] + v * c.vertical[1] - c.origin[1];
+    r.d.z = c.lower_left_corner[2] + u * c.horizontal[2] + v * c.vertical[2] - c.origin[2];
+    const float a = dot3(r.d, r.d);
+    float closest = FLT_MAX; int best = -1;
+#ifdef RT_STATS
+    Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
+    for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
+#endif
+    if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, inside, closest, best STAT_PASS);
+    else closest_list(A.scene, r, a, closest, best);
+    int w = 0;
+    if (inside) {
+        w = 1;                                             // sky: one ray per sample
+        if (best >= 0) {
+            const int kind = A.scene.kind[best];
+            w = kind == RT_MAT_DIELECTRIC ? 12 : (kind == RT_MAT_METAL ? 4 : 3);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+    if (lane == 0) cost[local_tile] = w;
+}
+
+RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (c > 7 ? 7 : c); }
+
+// one wave: stable counting sort of the tiles by cost class, descending
+__global__ __launch_bounds__(64) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n) {
+    const int lane = threadIdx.x;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long t = lane; t < n; t += 64) {
+        const int c = cost_class(cost[t]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cnt[k] += (c == k) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        for (int off = 32; off > 0; off >>= 1) cnt[k] += __shfl_xor(cnt[k], off);
+    long long base[8];
+    long long run = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) { base[k] = run; run += cnt[k]; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (long long t0 = 0; t0 < n; t0 += 64) {
+        const long long t = t0 + lane;
+        const int c = t < n ? cost_class(cost[t]) : -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long m = __ballot(c == k);
+            if (c == k) order[base[k] + __popcll(m & lt)] = (unsigned int)t;
+            base[k] += __popcll(m);
+        }
+    }
 }
 
 // hitTree / hitable_list::hit for a batch of rays (one lane per ray)
@@ -593,6 +772,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene S, DevTree T, const floa
     float closest = FLT_MAX; int best = -1;
 #ifdef RT_STATS
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
+    for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
 #endif
     if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best STAT_PASS);
     else closest_list(S, r, a, closest, best);
@@ -640,6 +820,16 @@ template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024u;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
     return (unsigned)(cus * per_cu);
+}
+
+hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, hipStream_t st) {
+    if (A.n_local_tiles <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((A.n_local_tiles + 3) / 4);
+    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
+    if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), lds, st, A, cost);
+    else hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), lds, st, A, cost);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(64), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
+    return hipGetLastError();
 }
 
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {

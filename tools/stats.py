@@ -10,11 +10,11 @@ L = rt.lib()
 L.rt_debug_stats.restype = C.c_int
 L.rt_debug_stats.argtypes = [C.c_void_p, C.c_int]
 names = ["rays", "fast", "slow", "tie", "cols", "tests", "discpos", "offers", "elig", "elig_nodes", "A_iters_wave", "B_rounds_wave",
-         "loop_iters_wave", "A_lane_steps", "B_lanes", "waves"]
+         "loop_iters_wave", "A_lane_steps", "B_lanes", "waves", "live_ge56", "live_32_55", "live_8_31", "live_lt8", "switches"]
 n, nx, ny, ns, spl = (int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (10000, 1200, 800, 8, 32)))
 W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload()
 st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 24)()
 rt.render_init(nx, ny, st); torch.cuda.synchronize()
 L.rt_debug_stats(buf, 1)
 rt.render(fb, nx, ny, ns, W, st, O); torch.cuda.synchronize()
@@ -30,3 +30,17 @@ print("per wave: loop iters %.1f, A iters %.1f (%.1f per loop iter), B rounds %.
        v["B_rounds_wave"] / waves, v["B_rounds_wave"] / max(1, v["loop_iters_wave"])))
 print("lane utilisation: phase A %.3f, phase B %.3f, rays per loop iter %.2f of 64" %
       (v["A_lane_steps"] / max(1, 64 * v["A_iters_wave"]), v["B_lanes"] / max(1, 64 * v["B_rounds_wave"]), rays / max(1, v["loop_iters_wave"])))
+print("waves %d; loop iterations by live lanes: >=56: %.3f  32-55: %.3f  8-31: %.3f  <8: %.3f; pixel switches %d" % (
+    waves, *[v[k] / max(1, v["loop_iters_wave"]) for k in ("live_ge56", "live_32_55", "live_8_31", "live_lt8")], v["switches"]))
+
+import numpy as np
+img = fb.cpu().numpy().reshape(ny, nx, 3)
+it, stp = img[:, :, 0], img[:, :, 1]
+print("per-pixel loop iterations: mean %.1f  p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f" % (it.mean(), *np.percentile(it, [50, 90, 99, 99.9]), it.max()))
+print("per-pixel walk steps:      mean %.1f  p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f" % (stp.mean(), *np.percentile(stp, [50, 90, 99, 99.9]), stp.max()))
+rows = it.mean(axis=1)
+print("row means of iterations (every 50 rows from bottom):", " ".join("%.0f" % rows[k] for k in range(0, ny, 50)))
+rows = stp.mean(axis=1)
+print("row means of walk steps (every 50 rows from bottom):", " ".join("%.0f" % rows[k] for k in range(0, ny, 50)))
+worst = np.argsort(it.ravel())[-5:]
+print("worst pixels (row, col, iters, steps):", [(int(w // nx), int(w % nx), int(it.ravel()[w]), int(stp.ravel()[w])) for w in worst])
