@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 CONFIGS = {
     "c2": dict(name="C2", nx=1200, ny=800, spp=64, spheres=500, octree=False, spl=30, flops_per_sample=18.2e3),
     "c3": dict(name="C3", nx=1200, ny=800, spp=64, spheres=10000, octree=True, spl=32, flops_per_sample=13.6e3),
+    "c4": dict(name="C4", nx=1200, ny=800, spp=64, spheres=10000, octree=True, spl=32, flops_per_sample=9.8e3, fp16=True),
 }
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate, spec
 PEAK_HBM_GBS = 8000.0
@@ -32,7 +33,7 @@ PEAK_HBM_GBS = 8000.0
 def cpu_baseline(cfg, rt_cores, use_octree, rows, spp):
     """the oracle ("port" of the reference algorithm) timed on this host's cores on a bounded sample of the workload"""
     from oracle_lib import OracleScene
-    S = OracleScene(cfg["spheres"], cfg["nx"], cfg["ny"], use_octree=use_octree, spl=cfg["spl"])
+    S = OracleScene(cfg["spheres"], cfg["nx"], cfg["ny"], fp16=bool(cfg.get("fp16")), use_octree=use_octree, spl=cfg["spl"])
     # rows spread over the frame so the sample sees sky, spheres and ground like the whole frame does
     picks = [int((k + 0.5) * cfg["ny"] / rows) for k in range(rows)]
     t0 = time.perf_counter()
@@ -89,15 +90,16 @@ def main():
     part = rt.Partition(rank, world)
 
     # scene: generated on the host exactly as create_world does (seed 1984), resident in HBM before the timed region
-    W = rt.World(cfg["spheres"], nx, ny).upload()
+    precision = rt.FP16 if cfg.get("fp16") else rt.FP32
+    W = rt.World(cfg["spheres"], nx, ny, precision=precision).upload()
     O = rt.Octree(W, cfg["spl"]).upload() if cfg["octree"] else None
     st = rt.alloc_rand_state(nx, ny, part)
-    fb = rt.alloc_fb(nx, ny, part)
+    fb = rt.alloc_fb(nx, ny, part, precision=precision)
     per = rt.part_pixels(nx, ny, rt.Partition(0, world))          # padded part size (largest part)
     if world > 1:
-        send = torch.zeros(per * 3, dtype=torch.float32, device="cuda")
-        parts = torch.zeros(world * per * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-        full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        send = torch.zeros(per * 3, dtype=fb.dtype, device="cuda")
+        parts = torch.zeros(world * per * 3, dtype=fb.dtype, device="cuda") if rank == 0 else None
+        full = torch.zeros(nx * ny * 3, dtype=fb.dtype, device="cuda") if rank == 0 else None
 
     ev = []
 
@@ -115,7 +117,7 @@ def main():
             gathered = rt_dist.gather_parts(dist, send, rank, world, dst=0)   # the single framebuffer exchange over xGMI
             if rank == 0:
                 torch.cat(gathered, out=parts)
-                rt.assemble(full, parts, nx, ny, world)
+                rt.assemble(full, parts, nx, ny, world, precision=precision)
 
     def fence():
         if world > 1:
@@ -153,12 +155,12 @@ def main():
         out = {
             "metric": "Msamples/s (W*H*spp/render_time) at 1200x800, 10k spheres", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d spp, NUM_SPHERES=%d, USE_OCTREE %s, SPHERES_PER_LEAF=%d, fp32, create_world seed 1984%s"
-                       % (cfg["name"], nx, ny, spp, cfg["spheres"], "on" if cfg["octree"] else "off", cfg["spl"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if cfg.get("fp16") else "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d spp, NUM_SPHERES=%d, USE_OCTREE %s, SPHERES_PER_LEAF=%d, %s, create_world seed 1984%s"
+                       % (cfg["name"], nx, ny, spp, cfg["spheres"], "on" if cfg["octree"] else "off", cfg["spl"], "USE_FP16" if cfg.get("fp16") else "fp32",
                           "" if world == 1 else "; frame grown to %d x 960000 px, 8x8 tiles round-robin over %d GPUs, one RCCL gather" % (world, world)),
                        "timed_region": "render_init + render (+ gather + assemble when n_gpus>1), scene resident in HBM"},
-            "roofline": {"bound": "valu", "kernel": "k_render<%s,0>" % ("true" if cfg["octree"] else "false"),
+            "roofline": {"bound": "valu", "kernel": "%s<%s,0>" % ("k_render_h" if cfg.get("fp16") else "k_render", "true" if cfg["octree"] else "false"),
                          "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "flops_per_sample": cfg["flops_per_sample"],

@@ -15,6 +15,9 @@ namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, hipStream_t st);
+hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st);
+hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
+hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y, int nparts, hipStream_t st);
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
 #ifdef RT_STATS
@@ -320,7 +323,6 @@ int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partiti
 static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
     if (!fb || !world || !d_rand_state || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
-    if (world->precision != RT_PRECISION_FP32) return RT_ENOTSUP;
     int rc = rt_world_upload(const_cast<rt_world*>(world));
     if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
     if (rc) return rc;
@@ -337,6 +339,7 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
     A.order = nullptr;
+    if (world->precision == RT_PRECISION_FP16) return (int)launch_render_h(A, d_octree != nullptr, mode, (hipStream_t)stream);
     if (mode == 0 && ns >= 4) {
         // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame:
         // call rt_render once before capturing it into a hipGraph.
@@ -364,20 +367,21 @@ int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, co
 
 int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream) {
     if (!fb_full || !fb_parts || max_x <= 0 || max_y <= 0 || nparts < 1) return RT_EINVAL;
-    if (precision != RT_PRECISION_FP32) return RT_ENOTSUP;
+    if (precision == RT_PRECISION_FP16) return (int)launch_assemble_h(fb_full, fb_parts, max_x, max_y, nparts, (hipStream_t)stream);
+    if (precision != RT_PRECISION_FP32) return RT_EINVAL;
     return (int)launch_assemble((float*)fb_full, (const float*)fb_parts, max_x, max_y, nparts, (hipStream_t)stream);
 }
 
 int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float* d_rays, int64_t n, rt_hit_record* d_out, void* stream) {
     if (!world || !d_rays || !d_out || n < 0) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
-    if (world->precision != RT_PRECISION_FP32) return RT_ENOTSUP;
     int rc = rt_world_upload(const_cast<rt_world*>(world));
     if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
     if (rc) return rc;
     DevTree T;
     if (d_octree) { T = d_octree->dev; T.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&T, 0, sizeof(T));
+    if (world->precision == RT_PRECISION_FP16) return (int)launch_trace_h(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
     return (int)launch_trace(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
 
