@@ -22,6 +22,7 @@ hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const fl
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
 #ifdef RT_STATS
 hipError_t read_stats(unsigned long long* out, int reset);
+hipError_t read_wave_dbg(unsigned long long* out);
 #endif
 }
 
@@ -335,7 +336,7 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     A.scene = world->dev;
     rt_world* wm = const_cast<rt_world*>(world);
     A.queue = wm->d_queue + (size_t)(wm->launches++ % kQueueSlots) * kQueueStride;
-    RT_TRY(hipMemsetAsync(A.queue, 0, sizeof(unsigned int), (hipStream_t)stream));
+    RT_TRY(hipMemsetAsync(A.queue, 0, 2 * sizeof(unsigned int), (hipStream_t)stream));     // [0] work counter, [1] thin waves
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
     A.order = nullptr;
@@ -388,6 +389,7 @@ int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float*
 #ifdef RT_STATS
 // diagnostic build only (librt_amd_stats.so): 16 work counters, see rt_kernels.hip
 int rt_debug_stats(unsigned long long* out16, int reset) { return (int)read_stats(out16, reset); }
+int rt_debug_waves(unsigned long long* out) { return (int)read_wave_dbg(out); }
 #endif
 
 // ------------------------------------------------------------------------------------------------ output

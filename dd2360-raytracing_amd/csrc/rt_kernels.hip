@@ -39,6 +39,14 @@ namespace rt {
 #ifndef RT_VOTE_NUM
 #define RT_VOTE_NUM 2
 #endif
+// a pixel averaging at least this many bounces per sample is a long chain (the scene average is ~2.7)
+#ifndef RT_LONG_RATE
+#define RT_LONG_RATE 20
+#endif
+// waves with at most this many rays on the fast path walk the grid cooperatively (all lanes on one ray at a time)
+#ifndef RT_COOP_MAX
+#define RT_COOP_MAX 4
+#endif
 
 // Diagnostic build only (-DRT_STATS, tools/stats.sh): per-lane work counters, summed into a global array at kernel end.
 #ifdef RT_STATS
@@ -47,6 +55,7 @@ enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFE
        ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
+__device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
 struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
 #define STAT(st, k, v) ((st).c[k] += (v))
 #define STAT_ARG , Stats& st
@@ -227,47 +236,186 @@ RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float 
 //   A  every lane steps through its columns / entries (18-op discriminant only) until it holds a sphere with disc > 0;
 //   B  the lanes holding one take the roots (sqrt, divide) and, if it would win, the reference's slab test (eligible()).
 // Returns true when the result must be recomputed by the reference scan (exact tie between two tree spheres).
-RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, float a, float& best_t, int& best STAT_ARG) {
-    const DevAccel& A = T.acc;
-    bool tie = false;
-    for (int k = 0; k < A.n_large; ++k) {
-        const float cand = sphere_candidate(r, a, A.large_hot[k]);
-        offer(T, s_nodes, r, cand, A.large_id[k], -1, best_t, best, tie STAT_PASS);
-    }
-    const int32_t* __restrict__ cs = A.cs;
-    const float4* __restrict__ hot = A.hot;
+struct Walk {                // a ray's walk over the grid, in cell units along its major axis
+    int i, iend, coff;      // next column, end (exclusive, in travel direction), offset of the x- or z-major grid copy
+    float om_c, on_c, slope, dm_c;
+    bool fwd, walking;
+};
+
+// last column worth visiting once a hit at best_t is known: its entry edge is within back_c of the hit point
+RT_DEV void walk_clip(Walk& W, const DevAccel& A, float best_t) {
+    const float fG = (float)A.G, back_c = (A.rmax + 2e-3f) * A.inv_h;
+    const float pm = fminf(fmaxf(W.om_c + best_t * W.dm_c, -4.0f), fG + 4.0f);
+    if (W.fwd) W.iend = min(W.iend, (int)floorf(pm + back_c) + 1);
+    else W.iend = max(W.iend, (int)ceilf(pm - back_c - 1.0f) - 1);
+    if (W.fwd ? (W.i >= W.iend) : (W.i <= W.iend)) W.i = W.iend;
+}
+
+RT_DEV Walk walk_setup(const DevAccel& A, const RayF& r, float best_t, int best) {
+    Walk W;
     const int G = A.G;
     const float fG = (float)G;
     const float slack = 2e-3f;
     const bool xmajor = fabsf(r.d.x) >= fabsf(r.d.z);
     const float om = xmajor ? r.o.x : r.o.z, on = xmajor ? r.o.z : r.o.x;
     const float dm = xmajor ? r.d.x : r.d.z, dn = xmajor ? r.d.z : r.d.x;
-    const int coff = xmajor ? 0 : A.zoff;
+    W.coff = xmajor ? 0 : A.zoff;
     // everything below is in cell units (cell i spans [i, i+1) along either axis)
-    const float om_c = (om - A.g0) * A.inv_h, on_c = (on - A.g0) * A.inv_h;
-    const float dm_c = dm * A.inv_h;
+    W.om_c = (om - A.g0) * A.inv_h; W.on_c = (on - A.g0) * A.inv_h;
+    W.dm_c = dm * A.inv_h;
     const float s_c = slack * A.inv_h, back_c = (A.rmax + slack) * A.inv_h;
     // where the line crosses the planes y = ylo / y = yhi, measured along the major axis
-    const float rmy = dm_c / r.d.y;
-    const float mA = om_c + (A.ylo - r.o.y) * rmy, mB = om_c + (A.yhi - r.o.y) * rmy;
+    const float rmy = W.dm_c / r.d.y;
+    const float mA = W.om_c + (A.ylo - r.o.y) * rmy, mB = W.om_c + (A.yhi - r.o.y) * rmy;
     float mlo = fminf(mA, mB) - s_c, mhi = fmaxf(mA, mB) + s_c;
-    const bool fwd = dm > 0.0f;
-    if (fwd) mlo = fmaxf(mlo, om_c - back_c); else mhi = fminf(mhi, om_c + back_c);     // nothing behind the origin matters
+    W.fwd = dm > 0.0f;
+    if (W.fwd) mlo = fmaxf(mlo, W.om_c - back_c); else mhi = fminf(mhi, W.om_c + back_c);     // nothing behind the origin matters
     int ilo = (int)floorf(fminf(fmaxf(mlo, -1.0f), fG)), ihi = (int)floorf(fminf(fmaxf(mhi, -1.0f), fG));
-    bool walking = !(ihi < 0 || ilo > G - 1 || !(mlo <= mhi));
+    W.walking = !(ihi < 0 || ilo > G - 1 || !(mlo <= mhi));
     ilo = max(ilo, 0); ihi = min(ihi, G - 1);
+    W.i = W.fwd ? ilo : ihi;
+    W.iend = (W.fwd ? ihi : ilo) + (W.fwd ? 1 : -1);
+    W.slope = dn / dm;
+    if (best >= 0) walk_clip(W, A, best_t);
+    if (W.i == W.iend || (W.fwd ? (W.i > W.iend) : (W.i < W.iend))) W.walking = false;
+    return W;
+}
+
+// entry range [e0, e1) of the cells the line can touch inside column `col` (cell units, lower edge at col)
+RT_DEV void column_range(const DevAccel& A, const Walk& W, int col, int& e0, int& e1) {
+    const int G = A.G;
+    const float fG = (float)G, s_c = 2e-3f * A.inv_h;
+    const float u0 = W.on_c + ((float)col - W.om_c) * W.slope, u1 = u0 + W.slope;
+    const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
+    int k0 = (int)floorf(fminf(fmaxf(lo, -1.0f), fG)), k1 = (int)floorf(fminf(fmaxf(hi, -1.0f), fG));
+    e0 = 0; e1 = 0;
+    if (!(k1 < 0 || k0 > G - 1)) {
+        k0 = max(k0, 0); k1 = min(k1, G - 1);
+        const int cbase = W.coff + col * G;
+        e0 = A.cs[cbase + k0];
+        e1 = A.cs[cbase + k1 + 1];
+    }
+}
+
+RT_DEV float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+RT_DEV int bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// Cooperative walk for waves with only a few rays (thin waves: DESIGN.md §5.4).  One ray at a time, all 64 lanes: up to 8
+// columns' cell ranges are fetched at once, their entries are spread over the lanes, every lane tests ONE sphere, the
+// lanes holding a possible winner take the exact roots and the reference's slab test in parallel, and a wave-wide
+// minimum picks the hit.  Three memory round trips per chunk instead of one per step.  Same result as the per-lane walk:
+// the minimum over the eligible candidates; an exact tie between two different spheres sends the ray to the reference scan.
+RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, bool mine, float& best_t, int& best, bool& tie STAT_ARG) {
+    const DevAccel& A = T.acc;
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(mine && W.walking);
+    while (todo != 0ull) {
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        RayF q;                                              // lane L's ray, in every lane
+        q.o.x = bcast(r.o.x, L); q.o.y = bcast(r.o.y, L); q.o.z = bcast(r.o.z, L);
+        q.d.x = bcast(r.d.x, L); q.d.y = bcast(r.d.y, L); q.d.z = bcast(r.d.z, L);
+        const float qa = bcast(a, L);
+        Walk Q;
+        Q.i = bcast(W.i, L); Q.iend = bcast(W.iend, L); Q.coff = bcast(W.coff, L);
+        Q.om_c = bcast(W.om_c, L); Q.on_c = bcast(W.on_c, L); Q.slope = bcast(W.slope, L); Q.dm_c = bcast(W.dm_c, L);
+        Q.fwd = bcast((int)W.fwd, L) != 0; Q.walking = true;
+        float bt = bcast(best_t, L); int bi = bcast(best, L);
+        bool tieL = false;
+        const int stp = Q.fwd ? 1 : -1;
+        const float ra = __builtin_amdgcn_rcpf(qa);
+        while (Q.i != Q.iend) {
+            STAT(st, ST_A_ITERS_WAVE, 1);
+            const int left = Q.fwd ? (Q.iend - Q.i) : (Q.i - Q.iend);
+            const int ncol = left < 8 ? left : 8;
+            int eb = 0, cnt = 0;
+            if (lane < ncol) { int e1; column_range(A, Q, Q.i + lane * stp, eb, e1); cnt = e1 - eb; }
+            int incl = cnt;                                  // inclusive prefix over lanes 0..7
+            { int t = __shfl_up(incl, 1); if (lane >= 1) incl += t; t = __shfl_up(incl, 2); if (lane >= 2) incl += t; t = __shfl_up(incl, 4); if (lane >= 4) incl += t; }
+            const int total = bcast(incl, 7);
+            for (int base = 0; base < total; base += 64) {
+                const int jdx = base + lane;
+                const bool have = jdx < total;
+                int e = 0;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int inc_m = bcast(incl, m), cnt_m = bcast(cnt, m), eb_m = bcast(eb, m);
+                    if (jdx >= inc_m - cnt_m && jdx < inc_m) e = eb_m + (jdx - (inc_m - cnt_m));
+                }
+                float cand = __builtin_inff();
+                bool want = false;
+                if (have) {
+                    STAT(st, ST_TESTS, 1);
+                    const float4 s = A.hot[e];
+                    const float ocx = q.o.x - s.x, ocy = q.o.y - s.y, ocz = q.o.z - s.z;
+                    const float b = ocx * q.d.x + ocy * q.d.y + ocz * q.d.z;
+                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
+                    const float disc = b * b - qa * c;
+                    if (disc > 0.0f) {
+                        const float sqa = __builtin_amdgcn_sqrtf(disc);
+                        const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
+                        const bool behind = (sqa - b) * ra + m < 0.001f;
+                        const bool beyond = (-b - sqa) * ra - m > bt;
+                        if (!behind && !beyond) {
+                            const float sq = sqrtf(disc);
+                            const float t1 = (-b - sq) / qa;
+                            if (t1 > 0.001f) cand = t1;
+                            else { const float t2 = (-b + sq) / qa; if (t2 > 0.001f) cand = t2; }
+                            want = cand <= bt;
+                        }
+                    }
+                }
+                if (__ballot(want) != 0ull) {
+                    STAT(st, ST_B_ROUNDS_WAVE, 1);
+                    int id = -1;
+                    bool elig = false;
+                    if (want) {
+                        id = A.id[e];
+                        const int nd = A.node1[e];
+                        if (cand < bt) {
+                            if (nd >= 0) { const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1]; elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y); }
+                            else elig = eligible(T, s_nodes, q, id STAT_PASS);
+                        }
+                    }
+                    // an equal t from a different tree sphere than the current best: the visit order would decide
+                    if (__ballot(want && cand == bt && id != bi && bi > 0) != 0ull) tieL = true;
+                    float mn = elig ? cand : __builtin_inff();
+                    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+                    if (mn < bt) {
+                        const unsigned long long mm = __ballot(elig && cand == mn);
+                        const int wid = bcast(id, __ffsll((long long)mm) - 1);
+                        if (__ballot(elig && cand == mn && id != wid) != 0ull) tieL = true;
+                        bt = mn; bi = wid;
+                    }
+                }
+            }
+            Q.i += ncol * stp;
+            if (bi >= 0) walk_clip(Q, A, bt);
+        }
+        if (lane == L) { best_t = bt; best = bi; tie = tie || tieL; W.walking = false; }
+    }
+}
+
+// Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
+// clipped to the y-slab that holds them, front to back, ending at the column that lies beyond the best hit.
+// The per-lane walk alternates two phases so that the expensive, rare work is done by many lanes at once:
+//   A  every lane steps through its columns / entries (18-op discriminant only) until it holds a sphere with disc > 0;
+//   B  the lanes holding one take the roots (sqrt, divide) and, if it would win, the reference's slab test (eligible()).
+// `tie` is set when the result must be recomputed by the reference scan (exact tie between two tree spheres).
+RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, float& best_t, int& best, bool& tie STAT_ARG) {
+    const DevAccel& A = T.acc;
+    const int32_t* __restrict__ cs = A.cs;
+    const float4* __restrict__ hot = A.hot;
+    const int G = A.G;
+    const float fG = (float)G;
+    const float s_c = 2e-3f * A.inv_h;
+    const float om_c = W.om_c, on_c = W.on_c, slope = W.slope;
+    const int coff = W.coff;
+    const bool fwd = W.fwd;
     const int step = fwd ? 1 : -1;
-    int i = fwd ? ilo : ihi;
-    int iend = (fwd ? ihi : ilo) + step;
-    const float slope = dn / dm;
-    // last column worth visiting once a hit at best_t is known: its entry edge is within back_c of the hit point
-    auto clip_to_hit = [&]() {
-        const float pm = fminf(fmaxf(om_c + best_t * dm_c, -4.0f), fG + 4.0f);
-        if (fwd) iend = min(iend, (int)floorf(pm + back_c) + 1);
-        else iend = max(iend, (int)ceilf(pm - back_c - 1.0f) - 1);
-    };
-    if (best >= 0) clip_to_hit();
-    if (fwd ? (i >= iend) : (i <= iend)) walking = false;
+    int i = W.i, iend = W.iend;
+    bool walking = W.walking;
+    auto clip_to_hit = [&]() { W.i = i; W.iend = iend; walk_clip(W, A, best_t); i = W.i; iend = W.iend; };
     int e = 0, e_end = 0;
     int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
     float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
@@ -372,7 +520,6 @@ RT_DEV bool tree_fast(const DevTree& T, const float4* s_nodes, const RayF& r, fl
         p_e = -1;
         }
     }
-    return tie;
 }
 
 // hitTree (acceleration_structure.h:319-342): ground sphere first, then the tree.
@@ -395,10 +542,20 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                           && (fabsf(r.d.y) >= 9.094947e-13f) && (zx * zx + zy * zy + zz * zz <= T.acc.zone2);
         slow = live && !fast;
         STAT(st, ST_FAST, fast ? 1 : 0); STAT(st, ST_SLOW, slow ? 1 : 0);
+        const float g_t = closest; const int g_id = best;
+        bool tie = false;
+        Walk W; W.walking = false; W.i = 0; W.iend = 0; W.coff = 0; W.om_c = 0.f; W.on_c = 0.f; W.slope = 0.f; W.dm_c = 0.f; W.fwd = true;
         if (fast) {
-            const float g_t = closest; const int g_id = best;
-            if (tree_fast(T, s_nodes, r, a, closest, best STAT_PASS)) { closest = g_t; best = g_id; slow = true; STAT(st, ST_TIE, 1); }
+            for (int k = 0; k < T.acc.n_large; ++k) {
+                const float cand = sphere_candidate(r, a, T.acc.large_hot[k]);
+                offer(T, s_nodes, r, cand, T.acc.large_id[k], -1, closest, best, tie STAT_PASS);
+            }
+            W = walk_setup(T.acc, r, closest, best);
         }
+        const int nf = __popcll(__ballot(fast));
+        if (nf > 0 && nf <= RT_COOP_MAX) walk_coop(T, s_nodes, r, a, W, fast, closest, best, tie STAT_PASS);
+        else if (fast) walk_lanes(T, s_nodes, r, a, W, closest, best, tie STAT_PASS);
+        if (fast && tie) { closest = g_t; best = g_id; slow = true; STAT(st, ST_TIE, 1); }
     }
 #ifdef RT_STATS
     const unsigned long long tS0 = TICK(); st.cyc[1] += tS0 - tG;     // fast path (large spheres + setup + walk), wave time
@@ -539,6 +696,15 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
 // (slot = local_tile*64 + ly*8 + lx, the 8x8 block shape of the reference); every lane starts on slot
 // (wave*64 + lane) and, when its pixel is finished, pulls the next unclaimed slot from a global counter, so no lane
 // waits for the slowest pixel of "its" tile.  Which lane renders a pixel does not affect the pixel (the RNG is per pixel).
+//
+// Long chains.  A pixel is a strictly serial chain of ns x bounces iterations, and a few pixels (crevices between a
+// sphere and the ground, glass) need 10-15x the average.  One iteration of a full wave costs ~40 k cycles, of a wave
+// with a single live lane ~16 k, so the frame cannot end before (longest chain) x (iteration time of ITS wave).
+// Therefore: slots are interleaved over blocks of 64 tiles (the 64 pixels of a tile go to 64 different lanes/waves: long
+// pixels cluster); a lane whose pixel shows >= RT_LONG_RATE bounces per sample (checked every 8 samples) marks it long;
+// a wave holding a long pixel stops refilling its other lanes ("thin" wave, raised issue priority) until that pixel is
+// finished, then resumes.  A global counter caps the
+// number of thin waves at a quarter of the grid, so a scene made of long pixels only keeps its throughput.
 template <bool TREE, int MODE>
 __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
@@ -552,8 +718,13 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     const long long first_free = (long long)gridDim.x * 256;       // slots below this are handed out statically
     const int ns = (MODE == 0) ? A.ns : 1;
 
+    const long long n_waves = (long long)gridDim.x * 4;
     long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
     int i = 0, j = 0; long long idx = 0;
+    unsigned int iters = 0;             // bounces spent on the current pixel
+    bool is_long = false;               // the current pixel has been classified long
+    bool retired = false;               // the queue was empty when this lane last asked
+    bool thin = false;                  // wave-uniform: this wave holds a long pixel and does not refill
     Rng s = {0, 0, 0, 0, 0, 0};
     V3 col = {0.0f, 0.0f, 0.0f};
     V3 att = {1.0f, 1.0f, 1.0f};
@@ -567,10 +738,19 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     // claim `slot` (skipping slots that fall outside the frame in edge tiles) and set the lane up for that pixel
     auto begin_pixel = [&]() {
         live = false;
+#ifdef RT_ONLY_LANE
+        if (lane != RT_ONLY_LANE) return;                  // probe build: one pixel chain alone in its wave
+#endif
+        iters = 0; is_long = false;
         while (slot < n_slots) {
-            const long long rank = slot >> 6;                                  // position in the hand-out order
+            // Slots are interleaved over blocks of 64 tiles (in hand-out order): consecutive slots are the same pixel
+            // position of 64 different tiles, so the pixels of one tile (long chains cluster) never travel together.
+            const long long blk = slot >> 12;
+            const long long tiles_in_blk = (A.n_local_tiles - blk * 64) < 64 ? (A.n_local_tiles - blk * 64) : 64;
+            const long long within = slot & 4095;
+            const long long rank = blk * 64 + within % tiles_in_blk;          // position in the hand-out order
+            const int l = (int)(within / tiles_in_blk);
             const long long local_tile = A.order ? (long long)A.order[rank] : rank;
-            const int l = (int)(slot & 63);
             const long long tile = A.part + local_tile * A.nparts;
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
@@ -581,6 +761,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             }
             slot = first_free + (long long)atomicAdd(A.queue, 1u);
         }
+        if (!live) retired = true;
         if (live) {
             const rt_rand_state* st = A.rand_state + idx;
             s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
@@ -609,11 +790,37 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
     const unsigned long long tK0 = TICK(), rK0 = __builtin_amdgcn_s_memrealtime();
+    unsigned int dbg_thin_iters = 0, dbg_long = 0;
 #endif
     if (ns > 0) begin_pixel();
 
-    while (__ballot(live) != 0ull) {
+    const unsigned int thin_cap = (unsigned int)(n_waves / 4);
+    while (true) {
+        // ---- wave-level bookkeeping (uniform)
+        const unsigned long long m_live = __ballot(live);
+        const unsigned long long m_long = __ballot(live && is_long);
+        if (!thin && m_long != 0ull) {
+            // try to become a thin wave; if the cap is reached these pixels simply stay ordinary
+            unsigned int prev = 0;
+            if (lane == 0) prev = atomicAdd(A.queue + 1, 1u);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev < thin_cap) { thin = true; __builtin_amdgcn_s_setprio(3); }       // the chain is on the critical path: win issue arbitration
+            else { if (lane == 0) atomicSub(A.queue + 1, 1u); is_long = false; }
+        } else if (thin && m_long == 0ull) {
+            thin = false; __builtin_amdgcn_s_setprio(0);
+            if (lane == 0) atomicSub(A.queue + 1, 1u);
+        }
+        if (!thin) {
+            // idle lanes (their pixel ended while the wave was thin) go back to the queue
+            if (!live && !retired) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+        }
+        // thin implies a live long pixel; otherwise every lane that is not live has just found the queue empty
+        if (__ballot(live) == 0ull) break;
+        (void)m_live;
         STAT(st, ST_LOOP_ITERS_WAVE, 1);
+#ifdef RT_STATS
+        if (thin) ++dbg_thin_iters;
+#endif
 #ifdef RT_STATS
         { const int nl = __popcll(__ballot(live)); STAT(st, nl >= 56 ? ST_LIVE_GE56 : nl >= 32 ? ST_LIVE_32 : nl >= 8 ? ST_LIVE_8 : ST_LIVE_LT8, 1); }
 #endif
@@ -629,6 +836,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (live) { ++pix_iters; }
 #endif
         if (live) {
+            ++iters;
             bool done;                                     // this sample's path has ended
             if (best >= 0) {
                 const bool cont = scatter(A.scene, best, closest, r, att, s);
@@ -641,8 +849,16 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             }
             if (done) {
                 ++sample; depth = 0; att = {1.0f, 1.0f, 1.0f};
-                if (sample < ns) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
-                else {
+                if (sample < ns) {
+                    r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+                    // classify after every 4th sample while enough of the chain is left for it to matter
+                    if ((sample & 7) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_LONG_RATE * sample)) {
+#ifdef RT_STATS
+                        if (!is_long) ++dbg_long;
+#endif
+                        is_long = true;
+                    }
+                } else {
 #ifdef RT_STATS
                     pix_steps = st.c[ST_A_LANE_STEPS] - steps_mark; steps_mark = st.c[ST_A_LANE_STEPS];
 #endif
@@ -651,8 +867,8 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                     pix_iters = 0;
 #endif
                     STAT(st, ST_SWITCHES, 1);
-                    slot = first_free + (long long)atomicAdd(A.queue, 1u);
-                    begin_pixel();
+                    live = false; is_long = false;
+                    if (!thin) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
                 }
             }
         }
@@ -665,7 +881,13 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (lane_max) { int m = (int)st.c[q]; for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off)); if (lane == 0) atomicAdd(&g_stats[q], (unsigned long long)m); }
         else if (st.c[q] && (!wave_level || lane == 0)) atomicAdd(&g_stats[q], (unsigned long long)st.c[q]);
     }
+    { int nl = (int)dbg_long; for (int off = 32; off > 0; off >>= 1) nl += __shfl_xor(nl, off); dbg_long = (unsigned int)nl; }
     if (lane == 0) {
+        const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (wv < 8192) {
+            g_wave_dbg[wv * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+            g_wave_dbg[wv * 4 + 1] = st.c[ST_LOOP_ITERS_WAVE]; g_wave_dbg[wv * 4 + 2] = dbg_thin_iters; g_wave_dbg[wv * 4 + 3] = dbg_long;
+        }
         atomicAdd(&g_stats[ST_SAMPLES], 1ull);
         const unsigned long long tot = TICK() - tK0;
         atomicAdd(&g_stats[ST_CYC_TOTAL], tot);
@@ -869,6 +1091,7 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
 }
 
 #ifdef RT_STATS
+hipError_t read_wave_dbg(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_dbg), sizeof(unsigned long long) * 8192 * 4); }
 hipError_t read_stats(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * ST_N);
     if (e != hipSuccess) return e;

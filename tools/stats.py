@@ -14,7 +14,7 @@ names = ["rays", "fast", "slow", "tie", "cols", "tests", "discpos", "offers", "e
 n, nx, ny, ns, spl = (int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (10000, 1200, 800, 8, 32)))
 W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload()
 st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
-buf = (C.c_ulonglong * 24)()
+buf = (C.c_ulonglong * 64)()
 rt.render_init(nx, ny, st); torch.cuda.synchronize()
 L.rt_debug_stats(buf, 1)
 rt.render(fb, nx, ny, ns, W, st, O); torch.cuda.synchronize()
@@ -44,3 +44,13 @@ rows = stp.mean(axis=1)
 print("row means of walk steps (every 50 rows from bottom):", " ".join("%.0f" % rows[k] for k in range(0, ny, 50)))
 worst = np.argsort(it.ravel())[-5:]
 print("worst pixels (row, col, iters, steps):", [(int(w // nx), int(w % nx), int(it.ravel()[w]), int(stp.ravel()[w])) for w in worst])
+
+wb = (C.c_ulonglong * (8192 * 4))()
+L.rt_debug_waves.restype = C.c_int; L.rt_debug_waves.argtypes = [C.c_void_p]
+L.rt_debug_waves(wb)
+w = np.array(list(wb), dtype=np.float64).reshape(8192, 4)[:waves]
+t = (w[:, 0] - w[:, 0].min()) / 100.0 / 1000.0     # ms relative to the first wave to end
+print("wave end times (ms after the first wave ended): p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(t, [10, 50, 90, 99, 100])))
+print("waves that went thin: %d; long pixels detected %d; thin iterations: mean %.0f max %.0f" % ((w[:, 2] > 0).sum(), w[:, 3].sum(), w[:, 2][w[:, 2] > 0].mean() if (w[:, 2] > 0).any() else 0, w[:, 2].max()))
+late = np.argsort(t)[-8:]
+print("last waves (end ms, loop iters, thin iters, long px):", [(round(t[k], 1), int(w[k, 1]), int(w[k, 2]), int(w[k, 3])) for k in late])

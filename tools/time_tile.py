@@ -21,7 +21,7 @@ for row, col in [(317, 802), (100, 600), (700, 600)]:
         t0 = time.perf_counter(); rt.render(fb, nx, ny, ns, W, st, O, part); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("tile of pixel (%d,%d): %.2f ms alone" % (row, col, dt * 1e3))
     if os.environ.get("RT_STATS"):
-        buf = (C.c_ulonglong * 32)(); L.rt_debug_stats(buf, 1)
+        buf = (C.c_ulonglong * 64)(); L.rt_debug_stats(buf, 1)
         v = list(buf)
         names = ["total", "closest", "fastpath(large+setup+walk)", "ground test", "scan", "shade+loop", "realtime(100MHz)"]
         cyc = v[21:28]
