@@ -29,7 +29,7 @@ namespace rt {
 
 // minimum waves per SIMD the render kernel is compiled for (register budget 512/RT_RENDER_WAVES VGPRs per lane)
 #ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 4
+#define RT_RENDER_WAVES 3
 #endif
 // grid entries tested per walk step (loads in flight together)
 #ifndef RT_BATCH
