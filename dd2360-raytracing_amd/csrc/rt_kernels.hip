@@ -47,6 +47,10 @@ namespace rt {
 #ifndef RT_COOP_MAX
 #define RT_COOP_MAX 4
 #endif
+// list path: rays are scanned cooperatively (lanes = spheres) while live_rays * RT_LIST_COOP_COST <= list size
+#ifndef RT_LIST_COOP_COST
+#define RT_LIST_COOP_COST 16
+#endif
 
 // Diagnostic build only (-DRT_STATS, tools/stats.sh): per-lane work counters, summed into a global array at kernel end.
 #ifdef RT_STATS
@@ -132,10 +136,63 @@ RT_DEV bool ray_box(const RayF& r, float lox, float loy, float loz, float hix, f
 }
 
 // ---------------------------------------------------------------------------------------------------- closest hit
-// hitable_list::hit over the hittable spheres in list order.  `k` is wave-uniform: scalar loads.
-RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, float& closest, int& best) {
+RT_DEV float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+RT_DEV int bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// sphere::hit reduced to "which t would this sphere offer": the near root if it is > t_min, else the far root if that
+// is > t_min, else none (+inf).  The reference accepts exactly when that value is < closest_so_far (the far root is
+// never below the near root, so a rejected near root in range cannot be followed by an accepted far root).
+RT_DEV float sphere_candidate(const RayF& r, float a, const float4 s) {
+    const float ocx = r.o.x - s.x, ocy = r.o.y - s.y, ocz = r.o.z - s.z;
+    const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
+    const float disc = b * b - a * c;
+    float cand = __builtin_inff();
+    if (disc > 0.0f) {
+        const float sq = sqrtf(disc);
+        const float t1 = (-b - sq) / a;
+        if (t1 > 0.001f) cand = t1;
+        else {
+            const float t2 = (-b + sq) / a;
+            if (t2 > 0.001f) cand = t2;
+        }
+    }
+    return cand;
+}
+
+// hitable_list::hit over the hittable spheres in list order.
+// Full waves: the sphere index `k` is wave-uniform -> scalar loads, every lane tests its own ray against sphere k.
+// Thin waves (few live rays, e.g. the tail of a frame): one ray at a time with the 64 lanes testing 64 spheres per step;
+// the winner is the smallest offered t, the lowest list index among equal t — exactly what the sequential scan keeps.
+RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, float& closest, int& best) {
     const float4* __restrict__ hot = S.list_hot;
     const int n = S.n_list;
+    unsigned long long todo = __ballot(live);
+    if (__popcll(todo) * RT_LIST_COOP_COST <= n) {
+        const int lane = threadIdx.x & 63;
+        while (todo != 0ull) {
+            const int L = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            RayF q;
+            q.o.x = bcast(r.o.x, L); q.o.y = bcast(r.o.y, L); q.o.z = bcast(r.o.z, L);
+            q.d.x = bcast(r.d.x, L); q.d.y = bcast(r.d.y, L); q.d.z = bcast(r.d.z, L);
+            const float qa = bcast(a, L);
+            float my_t = FLT_MAX; int my_k = 0x7fffffff;
+            for (int base = 0; base < n; base += 64) {
+                const int k = base + lane;
+                if (k < n) {
+                    const float cand = sphere_candidate(q, qa, hot[k]);
+                    if (cand < my_t) { my_t = cand; my_k = k; }
+                }
+            }
+            float mn = my_t;
+            for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+            int km = (my_t == mn && my_k != 0x7fffffff) ? my_k : 0x7fffffff;
+            for (int off = 32; off > 0; off >>= 1) km = min(km, __shfl_xor(km, off));
+            if (lane == L && km != 0x7fffffff) { closest = mn; best = S.list_id[km]; }
+        }
+        return;
+    }
     for (int k = 0; k < n; ++k) {
         const float4 s = hot[k];
         sphere_test(r, a, s.x, s.y, s.z, s.w, k, closest, best);
@@ -172,27 +229,6 @@ RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, fl
         }
     }
     if (e_best >= 0) best = T.ent_id[e_best];
-}
-
-// sphere::hit reduced to "which t would this sphere offer": the near root if it is > t_min, else the far root if that
-// is > t_min, else none (+inf).  The reference accepts exactly when that value is < closest_so_far (the far root is
-// never below the near root, so a rejected near root in range cannot be followed by an accepted far root).
-RT_DEV float sphere_candidate(const RayF& r, float a, const float4 s) {
-    const float ocx = r.o.x - s.x, ocy = r.o.y - s.y, ocz = r.o.z - s.z;
-    const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
-    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
-    const float disc = b * b - a * c;
-    float cand = __builtin_inff();
-    if (disc > 0.0f) {
-        const float sq = sqrtf(disc);
-        const float t1 = (-b - sq) / a;
-        if (t1 > 0.001f) cand = t1;
-        else {
-            const float t2 = (-b + sq) / a;
-            if (t2 > 0.001f) cand = t2;
-        }
-    }
-    return cand;
 }
 
 // Is the sphere stored in a level-3 node that the reference's traversal visits for this ray?  With no zero direction
@@ -296,9 +332,6 @@ RT_DEV void column_range(const DevAccel& A, const Walk& W, int col, int& e0, int
         e1 = A.cs[cbase + k1 + 1];
     }
 }
-
-RT_DEV float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-RT_DEV int bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
 // Cooperative walk for waves with only a few rays (thin waves: DESIGN.md §5.4).  One ray at a time, all 64 lanes: up to 8
 // columns' cell ranges are fetched at once, their entries are spread over the lanes, every lane tests ONE sphere, the
@@ -830,7 +863,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         const unsigned long long tC0 = TICK();
 #endif
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
-        else closest_list(A.scene, r, a, closest, best);
+        else closest_list(A.scene, r, a, live, closest, best);
 #ifdef RT_STATS
         const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0;
         if (live) { ++pix_iters; }
@@ -933,7 +966,7 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
 #endif
     if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, inside, closest, best STAT_PASS);
-    else closest_list(A.scene, r, a, closest, best);
+    else closest_list(A.scene, r, a, inside, closest, best);
     int w = 0;
     if (inside) {
         w = 1;                                             // sky: one ray per sample
@@ -997,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene S, DevTree T, const floa
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
 #endif
     if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best STAT_PASS);
-    else closest_list(S, r, a, closest, best);
+    else closest_list(S, r, a, live, closest, best);
     if (!live) return;
     rt_hit_record h;
     h.sphere = best; h.t = 0.f; h.p[0] = h.p[1] = h.p[2] = 0.f; h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
