@@ -14,7 +14,7 @@
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
-hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, hipStream_t st);
+hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y, int nparts, hipStream_t st);
@@ -44,7 +44,7 @@ struct rt_world {
     // queued on different streams never share one
     unsigned int* d_queue = nullptr; unsigned launches = 0;
     // scheduling workspace of rt_render (tile costs and hand-out order), grown on demand
-    int* d_cost = nullptr; unsigned int* d_order = nullptr; int64_t sched_tiles = 0;
+    int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
 };
 static const unsigned kQueueSlots = 64, kQueueStride = 16;
 
@@ -180,7 +180,7 @@ int rt_world_upload(rt_world* W) {
 int rt_free_world(rt_world* W) {
     if (!W) return 0;
     int rc = 0;
-    void* bufs[8] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue, W->d_cost, W->d_order};
+    void* bufs[10] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue, W->d_cost, W->d_order, W->d_flags, W->d_long};
     for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
     delete W;
     return rc;
@@ -336,10 +336,10 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     A.scene = world->dev;
     rt_world* wm = const_cast<rt_world*>(world);
     A.queue = wm->d_queue + (size_t)(wm->launches++ % kQueueSlots) * kQueueStride;
-    RT_TRY(hipMemsetAsync(A.queue, 0, 2 * sizeof(unsigned int), (hipStream_t)stream));     // [0] work counter, [1] thin waves
+    RT_TRY(hipMemsetAsync(A.queue, 0, 4 * sizeof(unsigned int), (hipStream_t)stream));
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
-    A.order = nullptr;
+    A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
     if (world->precision == RT_PRECISION_FP16) return (int)launch_render_h(A, d_octree != nullptr, mode, (hipStream_t)stream);
     if (mode == 0 && ns >= 4) {
         // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame:
@@ -347,13 +347,19 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
         if (wm->sched_tiles < A.n_local_tiles) {
             if (wm->d_cost) { RT_TRY(hipFree(wm->d_cost)); wm->d_cost = nullptr; }
             if (wm->d_order) { RT_TRY(hipFree(wm->d_order)); wm->d_order = nullptr; }
+            if (wm->d_flags) { RT_TRY(hipFree(wm->d_flags)); wm->d_flags = nullptr; }
+            if (wm->d_long) { RT_TRY(hipFree(wm->d_long)); wm->d_long = nullptr; }
             wm->sched_tiles = 0;
             RT_TRY(hipMalloc((void**)&wm->d_cost, sizeof(int) * (size_t)A.n_local_tiles));
             RT_TRY(hipMalloc((void**)&wm->d_order, sizeof(unsigned int) * (size_t)A.n_local_tiles));
+            RT_TRY(hipMalloc((void**)&wm->d_flags, (size_t)A.n_local_tiles * 64));
+            RT_TRY(hipMalloc((void**)&wm->d_long, sizeof(unsigned int) * (size_t)A.n_local_tiles * 64));
             wm->sched_tiles = A.n_local_tiles;
         }
-        RT_TRY(launch_tile_order(A, d_octree != nullptr, wm->d_cost, wm->d_order, (hipStream_t)stream));
+        const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long
+        RT_TRY(launch_tile_order(A, d_octree != nullptr, wm->d_cost, wm->d_order, classify ? wm->d_flags : nullptr, classify ? wm->d_long : nullptr, (hipStream_t)stream));
         A.order = wm->d_order;
+        if (classify) { A.long_flag = wm->d_flags; A.long_list = wm->d_long; }
     }
     return (int)launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream);
 }

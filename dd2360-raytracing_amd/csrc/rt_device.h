@@ -71,8 +71,10 @@ struct RenderArgs {
     int32_t tiles_x, tiles_y;
     int32_t part, nparts;
     int64_t n_local_tiles;
-    unsigned int* queue;                  // work counter of this launch (zeroed on the stream before the launch)
+    unsigned int* queue;                  // counters of this launch, zeroed on the stream: [0] work counter [1] thin waves [2] long chains [3] long head
     const unsigned int* order;            // hand-out order of the local tiles (most expensive first), or NULL = identity
+    const unsigned char* long_flag;       // per local pixel (local_tile*64 + l): pre-classified long chain, or NULL
+    const unsigned int* long_list;        // the pre-classified long chains (queue[2] = count, queue[3] = next to hand out)
     DevScene scene;
     DevTree tree;
 };

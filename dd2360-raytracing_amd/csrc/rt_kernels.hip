@@ -47,6 +47,17 @@ namespace rt {
 #ifndef RT_COOP_MAX
 #define RT_COOP_MAX 4
 #endif
+// pilot classification: a pixel whose RT_PILOT_SAMPLES pilot samples total at least RT_PILOT_LONG bounces is started as a long chain
+#ifndef RT_PILOT_SAMPLES
+#define RT_PILOT_SAMPLES 2
+#endif
+#ifndef RT_PILOT_LONG
+#define RT_PILOT_LONG 60
+#endif
+// long chains started per thin wave
+#ifndef RT_LONG_PER_WAVE
+#define RT_LONG_PER_WAVE 2
+#endif
 // list path: rays are scanned cooperatively (lanes = spheres) while live_rays * RT_LIST_COOP_COST <= list size
 #ifndef RT_LIST_COOP_COST
 #define RT_LIST_COOP_COST 16
@@ -56,7 +67,8 @@ namespace rt {
 #ifdef RT_STATS
 enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
        ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_LIVE_GE56, ST_LIVE_32, ST_LIVE_8, ST_LIVE_LT8, ST_SWITCHES,
-       ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME, ST_N };
+       ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME,
+       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
@@ -748,16 +760,23 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     }
     const int lane = threadIdx.x & 63;
     const long long n_slots = A.n_local_tiles * 64;
-    const long long first_free = (long long)gridDim.x * 256;       // slots below this are handed out statically
+    const long long first_free = 0;                                // every slot is handed out by the work counter
     const int ns = (MODE == 0) ? A.ns : 1;
 
     const long long n_waves = (long long)gridDim.x * 4;
-    long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    long long slot = 0;
     int i = 0, j = 0; long long idx = 0;
     unsigned int iters = 0;             // bounces spent on the current pixel
     bool is_long = false;               // the current pixel has been classified long
     bool retired = false;               // the queue was empty when this lane last asked
     bool thin = false;                  // wave-uniform: this wave holds a long pixel and does not refill
+    bool thin_counted = false;          // wave-uniform: this wave is included in the global thin-wave count
+    bool long_done = false;             // the list of pre-classified long chains is exhausted
+    // pre-classified long chains are honoured only while they are rare (<= 1/64 of the pixels): a scene made of long
+    // chains only must keep its throughput.  The same value is read by every wave, so the decision is grid-wide.
+    const unsigned int n_long_raw = A.long_list ? A.queue[2] : 0u;
+    const bool use_long = n_long_raw != 0u && (long long)n_long_raw * 64 <= n_slots;
+    const unsigned int n_long = use_long ? n_long_raw : 0u;
     Rng s = {0, 0, 0, 0, 0, 0};
     V3 col = {0.0f, 0.0f, 0.0f};
     V3 att = {1.0f, 1.0f, 1.0f};
@@ -787,7 +806,8 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             const long long tile = A.part + local_tile * A.nparts;
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
-            if (i < A.max_x && j < A.max_y) {
+            const bool taken = use_long && A.long_flag[local_tile * 64 + l];      // long chains are handed out separately
+            if (i < A.max_x && j < A.max_y && !taken) {
                 idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l;
                 live = true;
                 break;
@@ -801,6 +821,25 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             col = {0.0f, 0.0f, 0.0f}; att = {1.0f, 1.0f, 1.0f}; sample = 0; depth = 0;
             r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
         }
+    };
+    // take the next pre-classified long chain, if any is left (lanes 0..RT_LONG_PER_WAVE-1 only)
+    auto begin_long_pixel = [&]() -> bool {
+        if (!use_long || long_done) return false;
+        const unsigned int h = atomicAdd(A.queue + 3, 1u);
+        if (h >= n_long) { long_done = true; return false; }
+        const long long pid = (long long)A.long_list[h];
+        const long long local_tile = pid >> 6;
+        const int l = (int)(pid & 63);
+        const long long tile = A.part + local_tile * A.nparts;
+        const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+        i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
+        idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
+        live = true; iters = 0; is_long = true;
+        const rt_rand_state* st = A.rand_state + idx;
+        s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
+        col = {0.0f, 0.0f, 0.0f}; att = {1.0f, 1.0f, 1.0f}; sample = 0; depth = 0;
+        r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+        return true;
     };
     // rand_state[pixel_index] = local_rand_state; fb[pixel_index] = ...  (main.cu:110-115 / :133-141)
     auto end_pixel = [&]() {
@@ -824,8 +863,12 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
     const unsigned long long tK0 = TICK(), rK0 = __builtin_amdgcn_s_memrealtime();
     unsigned int dbg_thin_iters = 0, dbg_long = 0;
+    unsigned long long dbg_thin_cyc = 0, dbg_thin_closest = 0, dbg_thin1_cyc = 0; unsigned int dbg_thin1_iters = 0; unsigned long long dbg_t_prev = TICK();
 #endif
-    if (ns > 0) begin_pixel();
+    // start: pre-classified long chains first, RT_LONG_PER_WAVE per wave, in waves that are thin from the beginning
+    if (lane < RT_LONG_PER_WAVE) begin_long_pixel();
+    if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
+    else { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
 
     const unsigned int thin_cap = (unsigned int)(n_waves / 4);
     while (true) {
@@ -837,11 +880,12 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             unsigned int prev = 0;
             if (lane == 0) prev = atomicAdd(A.queue + 1, 1u);
             prev = __builtin_amdgcn_readfirstlane(prev);
-            if (prev < thin_cap) { thin = true; __builtin_amdgcn_s_setprio(3); }       // the chain is on the critical path: win issue arbitration
+            if (prev < thin_cap) { thin = true; thin_counted = true; __builtin_amdgcn_s_setprio(3); }       // the chain is on the critical path: win issue arbitration
             else { if (lane == 0) atomicSub(A.queue + 1, 1u); is_long = false; }
         } else if (thin && m_long == 0ull) {
             thin = false; __builtin_amdgcn_s_setprio(0);
-            if (lane == 0) atomicSub(A.queue + 1, 1u);
+            if (thin_counted && lane == 0) atomicSub(A.queue + 1, 1u);
+            thin_counted = false;
         }
         if (!thin) {
             // idle lanes (their pixel ended while the wave was thin) go back to the queue
@@ -852,7 +896,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         (void)m_live;
         STAT(st, ST_LOOP_ITERS_WAVE, 1);
 #ifdef RT_STATS
-        if (thin) ++dbg_thin_iters;
+        { const unsigned long long now = TICK(); const int nl2 = __popcll(__ballot(live));
+          if (thin) { ++dbg_thin_iters; dbg_thin_cyc += now - dbg_t_prev; if (nl2 <= 2) { ++dbg_thin1_iters; dbg_thin1_cyc += now - dbg_t_prev; } }
+          dbg_t_prev = now; }
 #endif
 #ifdef RT_STATS
         { const int nl = __popcll(__ballot(live)); STAT(st, nl >= 56 ? ST_LIVE_GE56 : nl >= 32 ? ST_LIVE_32 : nl >= 8 ? ST_LIVE_8 : ST_LIVE_LT8, 1); }
@@ -865,7 +911,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
 #ifdef RT_STATS
-        const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0;
+        const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0; if (thin) dbg_thin_closest += tC1 - tC0;
         if (live) { ++pix_iters; }
 #endif
         if (live) {
@@ -901,7 +947,8 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 #endif
                     STAT(st, ST_SWITCHES, 1);
                     live = false; is_long = false;
-                    if (!thin) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+                    if (lane < RT_LONG_PER_WAVE && begin_long_pixel()) { /* next long chain */ }
+                    else if (!thin) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
                 }
             }
         }
@@ -920,6 +967,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (wv < 8192) {
             g_wave_dbg[wv * 4 + 0] = __builtin_amdgcn_s_memrealtime();
             g_wave_dbg[wv * 4 + 1] = st.c[ST_LOOP_ITERS_WAVE]; g_wave_dbg[wv * 4 + 2] = dbg_thin_iters; g_wave_dbg[wv * 4 + 3] = dbg_long;
+            atomicAdd(&g_stats[ST_SPARE0], dbg_thin_cyc); atomicAdd(&g_stats[ST_SPARE1], dbg_thin_closest); atomicAdd(&g_stats[ST_SPARE2], dbg_thin1_cyc); atomicAdd(&g_stats[ST_SPARE3], (unsigned long long)dbg_thin1_iters); atomicAdd(&g_stats[ST_SPARE4], (unsigned long long)dbg_thin_iters);
         }
         atomicAdd(&g_stats[ST_SAMPLES], 1ull);
         const unsigned long long tot = TICK() - tK0;
@@ -934,11 +982,12 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 // ---------------------------------------------------------------------------------------------------- scheduling
 // Longest-processing-time-first hand-out order for the persistent render kernel.  A pixel is a strictly serial chain
 // (ns samples x bounces on one RNG stream); with only a few pixels per resident lane, a long chain picked up late keeps
-// a nearly empty wave running.  k_tile_cost shoots one deterministic centre ray per pixel (no RNG is touched) and
-// weighs what it hits (glass paths are long, sky paths are one ray); k_tile_order sorts the tiles into 8 cost classes,
-// most expensive first, stably.  The order changes only WHICH lane renders a pixel, never the pixel.
+// a nearly empty wave running.  k_tile_cost traces one PILOT sample per pixel on a private RNG stream and counts its
+// bounces: the tile sums feed k_tile_order (8 cost classes, most expensive first, stable), and pixels whose pilot path
+// reaches RT_PILOT_LONG bounces are listed as long chains, which the render kernel starts first, in thin waves.
+// All of this changes only WHICH lane renders a pixel and WHEN, never the pixel.
 template <bool TREE>
-__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost) {
+__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ long_flag, unsigned int* __restrict__ long_list) {
     extern __shared__ float4 s_nodes[];
     if (TREE) {
         const int n4 = A.tree.n_nodes * 3;
@@ -952,29 +1001,41 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
     const bool inside = (i < A.max_x) && (j < A.max_y);
-    const rt_camera& c = A.scene.cam;
-    const float u = ((float)i + 0.5f) / (float)A.max_x, v = ((float)j + 0.5f) / (float)A.max_y;
-    RayF r;
-    r.o = {c.origin[0], c.origin[1], c.origin[2]};
-    r.d.x = c.lower_left_corner[0] + u * c.horizontal[0] + v * c.vertical[0] - c.origin[0];
-    r.d.y = c.lower_left_corner[1] + u * c.horizontal[1] + v * c.vertical[1] - c.origin[1];
-    r.d.z = c.lower_left_corner[2] + u * c.horizontal[2] + v * c.vertical[2] - c.origin[2];
-    const float a = dot3(r.d, r.d);
-    float closest = FLT_MAX; int best = -1;
+    // PILOT path: one sample per pixel on a private RNG stream (seeded away from the pixel's own 1984 + pixel_index
+    // stream, which is not touched), same camera / closest-hit / scatter code as the render kernel; only the number
+    // of bounces is kept.
+    Rng ps; rng_seed(ps, 0x5deece66dull + (unsigned long long)((long long)j * A.max_x + i));
+    RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
+    V3 att = {1.0f, 1.0f, 1.0f};
+    bool live = inside;
+    if (live) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, ps);
+    int bounces = 0, depth = 0, sample = 0;
 #ifdef RT_STATS
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
 #endif
-    if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, inside, closest, best STAT_PASS);
-    else closest_list(A.scene, r, a, inside, closest, best);
-    int w = 0;
-    if (inside) {
-        w = 1;                                             // sky: one ray per sample
-        if (best >= 0) {
-            const int kind = A.scene.kind[best];
-            w = kind == RT_MAT_DIELECTRIC ? 12 : (kind == RT_MAT_METAL ? 4 : 3);
+    while (__ballot(live) != 0ull) {
+        const float a = dot3(r.d, r.d);
+        float closest = FLT_MAX; int best = -1;
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
+        else closest_list(A.scene, r, a, live, closest, best);
+        if (live) {
+            ++bounces; ++depth;
+            bool done = true;
+            if (best >= 0) { const bool cont = scatter(A.scene, best, closest, r, att, ps); done = !cont || depth >= 50; }
+            if (done) {
+                ++sample; depth = 0;
+                if (sample < RT_PILOT_SAMPLES) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, ps);
+                else live = false;
+            }
         }
     }
+    const bool is_long = inside && bounces >= RT_PILOT_LONG;
+    if (long_flag) {
+        long_flag[local_tile * 64 + lane] = is_long ? 1 : 0;
+        if (is_long) { const unsigned int pos = atomicAdd(A.queue + 2, 1u); long_list[pos] = (unsigned int)(local_tile * 64 + lane); }
+    }
+    int w = inside ? bounces : 0;
     for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
     if (lane == 0) cost[local_tile] = w;
 }
@@ -1077,12 +1138,12 @@ template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
     return (unsigned)(cus * per_cu);
 }
 
-hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, hipStream_t st) {
+hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((A.n_local_tiles + 3) / 4);
     const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
-    if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), lds, st, A, cost);
-    else hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), lds, st, A, cost);
+    if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), lds, st, A, cost, flags, long_list);
+    else hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), lds, st, A, cost, flags, long_list);
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(64), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
     return hipGetLastError();
 }

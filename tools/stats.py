@@ -19,7 +19,8 @@ rt.render_init(nx, ny, st); torch.cuda.synchronize()
 L.rt_debug_stats(buf, 1)
 rt.render(fb, nx, ny, ns, W, st, O); torch.cuda.synchronize()
 L.rt_debug_stats(buf, 1)
-v = dict(zip(names, list(buf)))
+raw = list(buf)
+v = dict(zip(names, raw))
 rays = max(1, v["rays"]); samples = nx * ny * ns; waves = max(1, v["waves"])
 print("accel", O.accel_info())
 print("samples %d rays/sample %.3f fast %.4f slow %.5f ties %d" % (samples, rays / samples, v["fast"] / rays, v["slow"] / rays, v["tie"]))
@@ -54,3 +55,8 @@ print("wave end times (ms after the first wave ended): p10 %.1f p50 %.1f p90 %.1
 print("waves that went thin: %d; long pixels detected %d; thin iterations: mean %.0f max %.0f" % ((w[:, 2] > 0).sum(), w[:, 3].sum(), w[:, 2][w[:, 2] > 0].mean() if (w[:, 2] > 0).any() else 0, w[:, 2].max()))
 late = np.argsort(t)[-8:]
 print("last waves (end ms, loop iters, thin iters, long px):", [(round(t[k], 1), int(w[k, 1]), int(w[k, 2]), int(w[k, 3])) for k in late])
+
+sp = raw[28:33]
+if sp[4]:
+    print("thin waves under load: %.1f k cycles per thin iteration (closest %.1f k); with <= 2 live lanes: %.1f k cycles per iteration (%d iterations)" % (
+        sp[0] / sp[4] / 1e3, sp[1] / sp[4] / 1e3, sp[2] / max(1, sp[3]) / 1e3, sp[3]))
