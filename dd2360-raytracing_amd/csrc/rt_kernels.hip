@@ -995,12 +995,15 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (local_tile >= A.n_local_tiles) return;
-    const long long tile = A.part + local_tile * A.nparts;
+    // quarter resolution: one pilot pixel per 2x2 block (long chains cluster); a wave covers four tiles, 16 lanes each
+    const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool tile_ok = local_tile < A.n_local_tiles;
+    const long long tile = A.part + (tile_ok ? local_tile : 0) * A.nparts;
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
-    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
-    const bool inside = (i < A.max_x) && (j < A.max_y);
+    const int sub = lane & 15;
+    const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
+    const int i = tx * 8 + lx, j = ty * 8 + ly;
+    const bool inside = tile_ok && (i < A.max_x) && (j < A.max_y);
     // PILOT path: one sample per pixel on a private RNG stream (seeded away from the pixel's own 1984 + pixel_index
     // stream, which is not touched), same camera / closest-hit / scatter code as the render kernel; only the number
     // of bounces is kept.
@@ -1031,13 +1034,19 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
         }
     }
     const bool is_long = inside && bounces >= RT_PILOT_LONG;
-    if (long_flag) {
-        long_flag[local_tile * 64 + lane] = is_long ? 1 : 0;
-        if (is_long) { const unsigned int pos = atomicAdd(A.queue + 2, 1u); long_list[pos] = (unsigned int)(local_tile * 64 + lane); }
+    if (long_flag && tile_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                          // the 2x2 block this pilot pixel stands for
+            const int px = lx + (q & 1), py = ly + (q >> 1);
+            const bool in_img = (tx * 8 + px < A.max_x) && (ty * 8 + py < A.max_y);
+            const long long pid = local_tile * 64 + py * 8 + px;
+            long_flag[pid] = (is_long && in_img) ? 1 : 0;
+            if (is_long && in_img) { const unsigned int pos = atomicAdd(A.queue + 2, 1u); long_list[pos] = (unsigned int)pid; }
+        }
     }
     int w = inside ? bounces : 0;
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
-    if (lane == 0) cost[local_tile] = w;
+    for (int off = 8; off > 0; off >>= 1) w += __shfl_xor(w, off);         // sum over the tile's 16 pilot pixels
+    if (sub == 0 && tile_ok) cost[local_tile] = w * 4;
 }
 
 RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (c > 7 ? 7 : c); }
@@ -1140,7 +1149,7 @@ template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
 
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((A.n_local_tiles + 3) / 4);
+    const unsigned blocks = (unsigned)((A.n_local_tiles + 15) / 16);       // a wave covers four tiles
     const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
     if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), lds, st, A, cost, flags, long_list);
     else hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), lds, st, A, cost, flags, long_list);
