@@ -25,6 +25,28 @@ template <class Body> static void parallel_rows(int rows, int nthreads, Body bod
     for (auto& x : th) x.join();
 }
 
+// A world given by the caller instead of create_world (tests of arbitrary scenes): geom N x (cx,cy,cz,r),
+// mat N x (albedo rgb, param), kind N (MAT_*; -1 = ghost slot), cam = 22 floats in camera.h field order.
+// Values are converted to real_t exactly as the product converts them (float images).
+template <class R> static void fill_custom(World<R>& W, int n, const float* geom, const float* mat, const int32_t* kind, const float* cam, bool use_octree, int spl) {
+    W.use_octree = use_octree;
+    W.list.resize(n);
+    int real = 0;
+    for (int i = 0; i < n; ++i) {
+        Sphere<R>& sp = W.list[i];
+        for (int k = 0; k < 3; ++k) { sp.center.e[k] = from_f<R>(geom[i * 4 + k]); sp.albedo.e[k] = from_f<R>(mat[i * 4 + k]); }
+        sp.radius = from_f<R>(geom[i * 4 + 3]); sp.param = from_f<R>(mat[i * 4 + 3]); sp.kind = kind[i];
+        if (kind[i] != MAT_NONE) ++real;
+    }
+    W.n_real = real; W.world_draws = 0;
+    xorwow_init(W.world_rng_after, 1984);
+    int o = 0;
+    auto get = [&](V3<R>& v) { for (int k = 0; k < 3; ++k) v.e[k] = from_f<R>(cam[o++]); };
+    get(W.cam.origin); get(W.cam.lower_left_corner); get(W.cam.horizontal); get(W.cam.vertical); get(W.cam.u); get(W.cam.v); get(W.cam.w);
+    W.cam.lens_radius = from_f<R>(cam[o++]);
+    if (use_octree) W.tree = build_octree(W.list, spl);
+}
+
 extern "C" {
 
 orc_scene* orc_scene_create(int num_spheres, float radius, int nx, int ny, int fp16, int use_octree, int spl) {
@@ -34,6 +56,14 @@ orc_scene* orc_scene_create(int num_spheres, float radius, int nx, int ny, int f
     else s->w32 = create_world<float>(num_spheres, radius, nx, ny, use_octree != 0, spl);
     return s;
 }
+orc_scene* orc_scene_create_custom(int n, const float* geom, const float* mat, const int32_t* kind, const float* cam, int nx, int ny, int fp16, int use_octree, int spl) {
+    orc_scene* s = new orc_scene();
+    s->fp16 = fp16; s->num_spheres = n; s->nx = nx; s->ny = ny; s->spl = spl;
+    if (fp16) fill_custom(s->w16, n, geom, mat, kind, cam, use_octree != 0, spl);
+    else fill_custom(s->w32, n, geom, mat, kind, cam, use_octree != 0, spl);
+    return s;
+}
+
 void orc_scene_destroy(orc_scene* s) { delete s; }
 
 // out: [0] slots [1] real [2] world draws [3] nodeCount [4] leafCount [5] leaf entries [6] dropped (buckets full) [7] dropped (outside root)

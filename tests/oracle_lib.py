@@ -29,6 +29,8 @@ def lib():
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_create_custom.restype = C.c_void_p
+        L.orc_scene_create_custom.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_scene_info.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_scene_spheres.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.orc_scene_camera.argtypes = [C.c_void_p, C.c_void_p]
@@ -64,10 +66,17 @@ def _p(a):
 class OracleScene:
     """create_world + buildOctree of the reference (main.cu:146-204, acceleration_structure.h:195) on the CPU."""
 
-    def __init__(self, num_spheres, nx, ny, radius=0.1, fp16=False, use_octree=False, spl=30):
+    def __init__(self, num_spheres, nx, ny, radius=0.1, fp16=False, use_octree=False, spl=30, custom=None):
+        """custom = (geom Nx4, mat Nx4, kind N, camera 22 floats): a caller-supplied world instead of create_world"""
         self.L = lib()
         self.n, self.nx, self.ny, self.fp16, self.use_octree, self.spl = num_spheres, nx, ny, bool(fp16), bool(use_octree), spl
-        self.h = C.c_void_p(self.L.orc_scene_create(num_spheres, radius, nx, ny, int(fp16), int(use_octree), spl))
+        if custom is None:
+            self.h = C.c_void_p(self.L.orc_scene_create(num_spheres, radius, nx, ny, int(fp16), int(use_octree), spl))
+        else:
+            geom, mat, kind, cam = (np.ascontiguousarray(custom[0], np.float32), np.ascontiguousarray(custom[1], np.float32),
+                                    np.ascontiguousarray(custom[2], np.int32), np.ascontiguousarray(custom[3], np.float32))
+            assert geom.shape == (num_spheres, 4) and mat.shape == (num_spheres, 4) and kind.shape == (num_spheres,) and cam.size == 22
+            self.h = C.c_void_p(self.L.orc_scene_create_custom(num_spheres, _p(geom), _p(mat), _p(kind), _p(cam), nx, ny, int(fp16), int(use_octree), spl))
 
     def close(self):
         if self.h:

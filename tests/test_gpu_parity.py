@@ -352,3 +352,71 @@ def test_fp16_c4_properties_and_psnr(rt, cuda):
     b = np.clip(np.nan_to_num(outs[0].float().cpu().numpy()), 0, 1)
     psnr = 10 * np.log10(1.0 / float(np.mean((a - b) ** 2)))
     assert 8.0 < psnr < 18.0, psnr
+
+
+# ---------------------------------------------------------------------------------------------------- arbitrary worlds
+def random_world(rt, seed, n, nx, ny, big=6, air=0.3, outside=0.05, ghosts=0.03):
+    """a caller-built world (not create_world): spheres of many sizes, in the air, overlapping, some outside the
+    octree's root box (dropped with the reference's 'not in range' message), some ghost slots, every material"""
+    rng = np.random.default_rng(seed)
+    sp = np.zeros(n, rt.sphere_dtype)
+    sp["center"][:, 0] = rng.uniform(-10.5, 10.5, n)
+    sp["center"][:, 2] = rng.uniform(-10.5, 10.5, n)
+    sp["radius"] = rng.choice([0.03, 0.05, 0.1, 0.1, 0.1, 0.15, 0.2, 0.3], n)
+    sp["center"][:, 1] = sp["radius"]
+    up = rng.random(n) < air
+    sp["center"][up, 1] = rng.uniform(0.0, 1.9, up.sum())
+    bigs = rng.choice(np.arange(1, n), big, replace=False)
+    sp["radius"][bigs] = rng.uniform(0.6, 1.4, big)
+    sp["center"][bigs, 1] = rng.uniform(0.2, 1.2, big)
+    out = rng.random(n) < outside
+    sp["center"][out, 0] = rng.uniform(11.5, 14.0, out.sum())
+    sp["material"] = rng.choice([rt.MAT_LAMBERTIAN, rt.MAT_LAMBERTIAN, rt.MAT_METAL, rt.MAT_DIELECTRIC], n)
+    sp["albedo"] = rng.uniform(0.05, 1.0, (n, 3))
+    sp["param"] = np.where(sp["material"] == rt.MAT_METAL, rng.uniform(0, 1, n), np.where(sp["material"] == rt.MAT_DIELECTRIC, 1.5, 0.0))
+    g = rng.random(n) < ghosts
+    g[0] = False
+    sp["material"][g] = rt.MAT_NONE
+    sp["center"][g] = 0; sp["radius"][g] = 0; sp["albedo"][g] = 0; sp["param"][g] = 0
+    sp[0] = ((0.0, -1000.0, -1.0), 1000.0, rt.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)      # ground stays slot 0 (hitTree tests it first)
+    cam = rt.camera_init((rng.uniform(8, 14), rng.uniform(1, 4), rng.uniform(-4, 4)), (0, 0.3, 0), (0, 1, 0), 35.0,
+                         np.float32(nx) / np.float32(ny), 0.05, 10.0)
+    return sp, cam
+
+
+def oracle_of(sp, cam, n, nx, ny, tree, spl):
+    geom = np.concatenate([sp["center"], sp["radius"][:, None]], 1)
+    mat = np.concatenate([sp["albedo"], sp["param"][:, None]], 1)
+    return OracleScene(n, nx, ny, use_octree=tree, spl=spl, custom=(geom, mat, sp["material"], cam.view(np.float32).ravel()))
+
+
+@pytest.mark.parametrize("seed,n,spl", [(1, 300, 30), (2, 3000, 40), (3, 12000, 64)])
+def test_arbitrary_world_hit_records_and_frames(rt, cuda, seed, n, spl):
+    """Worlds the caller builds itself: hit records (list, tree scan, tree fast) and a small frame equal the oracle."""
+    torch = cuda
+    nx, ny, ns = 72, 48, 3
+    sp, cam = random_world(rt, seed, n, nx, ny)
+    W = rt.World(n, nx, ny, spheres=sp, camera=cam)
+    O = rt.Octree(W, spl)
+    assert O.info()["dropped_outside"] > 0                       # the "not in range" path is exercised
+    nrays = 150_000
+    rays = random_rays(nrays, 500 + seed)
+    d_rays = torch.from_numpy(rays).cuda()
+    S_tree = oracle_of(sp, cam, n, nx, ny, True, spl)
+    ref_tree = S_tree.trace(rays, mode=2)
+    ref_list = S_tree.trace(rays, mode=1)
+    for name, oct_, mode, ref in (("list", None, None, ref_list), ("scan", O, rt.TRAVERSAL_REFERENCE, ref_tree), ("fast", O, rt.TRAVERSAL_FAST, ref_tree)):
+        if oct_ is not None:
+            oct_.set_traversal(mode)
+        d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+        rt.trace_rays(W, oct_, d_rays, nrays, d_out)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(rt.hit_record_dtype)
+        assert np.array_equal(got["sphere"], ref["sphere"]), name
+        assert np.array_equal(bits(got["t"]), bits(ref["t"])), name
+        assert np.array_equal(bits(got["normal"]), bits(ref["normal"])), name
+    O.set_traversal(rt.TRAVERSAL_FAST)
+    fb, st = gpu_render(rt, torch, W, O, nx, ny, ns)
+    ref, ref_st = S_tree.render(ns, nthreads=8)
+    assert np.array_equal(bits(fb.cpu().numpy().reshape(ny, nx, 3)), bits(ref))
+    assert np.array_equal(st.cpu().numpy().view(np.uint32).reshape(-1, 12)[:, :6], ref_st[:, :6])

@@ -155,3 +155,16 @@ def test_fp16_mode_sanity():
     mse = float(np.mean((np.clip(a, 0, 1) - np.clip(np.nan_to_num(b), 0, 1)) ** 2))
     psnr = 10 * np.log10(1.0 / mse)
     assert 6.0 < psnr < 20.0
+
+
+def test_custom_scene_entry_equals_create_world():
+    # the oracle's caller-supplied-world entry (used by the arbitrary-world GPU tests) fed with create_world's own
+    # output renders the same bits as the built-in path
+    S = OracleScene(500, 40, 24, use_octree=True, spl=30)
+    geom, mat, kind = S.spheres()
+    C = OracleScene(500, 40, 24, use_octree=True, spl=30, custom=(geom, mat, kind, S.camera()))
+    a, _ = S.render(3, nthreads=4)
+    b, _ = C.render(3, nthreads=4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    ia, ib = S.info(), C.info()
+    assert ia["node_count"] == ib["node_count"] and ia["leaf_entries"] == ib["leaf_entries"]
