@@ -33,7 +33,7 @@ namespace rt {
 #endif
 // grid entries tested per walk step (loads in flight together)
 #ifndef RT_BATCH
-#define RT_BATCH 8
+#define RT_BATCH 4
 #endif
 // phase B starts when holders * RT_VOTE_NUM >= searchers (or nobody searches)
 #ifndef RT_VOTE_NUM
@@ -313,7 +313,8 @@ RT_DEV Walk walk_setup(const DevAccel& A, const RayF& r, float best_t, int best)
     W.dm_c = dm * A.inv_h;
     const float s_c = slack * A.inv_h, back_c = (A.rmax + slack) * A.inv_h;
     // where the line crosses the planes y = ylo / y = yhi, measured along the major axis
-    const float rmy = W.dm_c / r.d.y;
+    // the walk's own parameters need no exact division: a few ulp are far inside the rasterisation slack
+    const float rmy = W.dm_c * __builtin_amdgcn_rcpf(r.d.y);
     const float mA = W.om_c + (A.ylo - r.o.y) * rmy, mB = W.om_c + (A.yhi - r.o.y) * rmy;
     float mlo = fminf(mA, mB) - s_c, mhi = fmaxf(mA, mB) + s_c;
     W.fwd = dm > 0.0f;
@@ -323,7 +324,7 @@ RT_DEV Walk walk_setup(const DevAccel& A, const RayF& r, float best_t, int best)
     ilo = max(ilo, 0); ihi = min(ihi, G - 1);
     W.i = W.fwd ? ilo : ihi;
     W.iend = (W.fwd ? ihi : ilo) + (W.fwd ? 1 : -1);
-    W.slope = dn / dm;
+    W.slope = dn * __builtin_amdgcn_rcpf(dm);
     if (best >= 0) walk_clip(W, A, best_t);
     if (W.i == W.iend || (W.fwd ? (W.i > W.iend) : (W.i < W.iend))) W.walking = false;
     return W;
@@ -648,8 +649,11 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
     V3 p, n;
     p.x = r.o.x + t * r.d.x; p.y = r.o.y + t * r.d.y; p.z = r.o.z + t * r.d.z;            // ray.h:13
     n.x = (p.x - g.x) / g.w; n.y = (p.y - g.y) / g.w; n.z = (p.z - g.z) / g.w;            // sphere.h:29
+    // lambertian and metal both draw exactly one random_in_unit_sphere and nothing else: one shared rejection loop
+    // (the slowest lane of a wave sets its length) instead of one per material branch; the draw order is unchanged
+    V3 q = {0.0f, 0.0f, 0.0f};
+    if (kind != RT_MAT_DIELECTRIC) q = random_in_unit_sphere(s);
     if (kind == RT_MAT_LAMBERTIAN) {                                                          // material.h:55-60
-        const V3 q = random_in_unit_sphere(s);
         const float tx = (p.x + n.x) + q.x, ty = (p.y + n.y) + q.y, tz = (p.z + n.z) + q.z;
         r.d.x = tx - p.x; r.d.y = ty - p.y; r.d.z = tz - p.z;
         r.o = p;
@@ -661,7 +665,6 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
         V3 ud; ud.x = r.d.x / len; ud.y = r.d.y / len; ud.z = r.d.z / len;
         const float k = 2.0f * dot3(ud, n);
         const float rx = ud.x - k * n.x, ry = ud.y - k * n.y, rz = ud.z - k * n.z;
-        const V3 q = random_in_unit_sphere(s);
         r.d.x = rx + m.w * q.x; r.d.y = ry + m.w * q.y; r.d.z = rz + m.w * q.z;
         r.o = p;
         att.x *= m.x; att.y *= m.y; att.z *= m.z;
