@@ -75,6 +75,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # test-only switches (tools/rehearse_2rank.sh): all ranks on GPU 0 with the gloo backend, so the whole N>1 flow can be
+    # rehearsed on a one-GPU box; the driver's runs never set them
+    same_gpu = os.environ.get("RT_BENCH_SAME_GPU") == "1"
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     rc, _ = rt.device_check()
     if rc != 0:
@@ -82,7 +88,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
     nx, ny = rt_dist.scaled_frame(cfg["nx"], cfg["ny"], world)
@@ -114,7 +123,11 @@ def main():
             ev.append((e0, e1))
         if world > 1:
             send[: fb.numel()].copy_(fb)
-            gathered = rt_dist.gather_parts(dist, send, rank, world, dst=0)   # the single framebuffer exchange over xGMI
+            if backend == "nccl":
+                gathered = rt_dist.gather_parts(dist, send, rank, world, dst=0)   # the single framebuffer exchange over xGMI
+            else:                                                                 # rehearsal: gloo moves host tensors
+                g = rt_dist.gather_parts(dist, send.cpu(), rank, world, dst=0)
+                gathered = [x.cuda() for x in g] if rank == 0 else None
             if rank == 0:
                 torch.cat(gathered, out=parts)
                 rt.assemble(full, parts, nx, ny, world, precision=precision)
@@ -133,9 +146,19 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if os.environ.get("RT_BENCH_CHECK") == "1" and rank == 0:
+            # rehearsal only: the assembled frame must equal a single-process render of the same frame
+            W1 = rt.World(cfg["spheres"], nx, ny, precision=precision).upload()
+            O1 = rt.Octree(W1, cfg["spl"]).upload() if cfg["octree"] else None
+            st1 = rt.alloc_rand_state(nx, ny); fb1 = rt.alloc_fb(nx, ny, precision=precision)
+            rt.render_init(nx, ny, st1); rt.render(fb1, nx, ny, spp, W1, st1, O1); torch.cuda.synchronize()
+            same = torch.equal(full.view(torch.int16 if cfg.get("fp16") else torch.int32), fb1.view(torch.int16 if cfg.get("fp16") else torch.int32))
+            print("rehearsal: assembled %d-rank frame %s the single-process frame" % (world, "EQUALS" if same else "DIFFERS FROM"), file=sys.stderr, flush=True)
+            if not same:
+                raise SystemExit(3)
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
     samples_step = nx * ny * spp                                  # whole job, all ranks
