@@ -22,6 +22,7 @@ struct AccelHost {
     std::vector<float4> large_hot; std::vector<int32_t> large_id;
     std::vector<int32_t> cs, id, node1; std::vector<float4> hot;     // x-major copy followed by z-major copy
     std::vector<int32_t> memb_start, memb_cell;
+    std::vector<int32_t> cellnode;                            // 8x8x8 level-3 cells of the root box -> pre-order node
     DevAccel p{};
 };
 
@@ -29,6 +30,7 @@ struct AccelHost {
 static const double kZone = 24.0;          // near zone: |o - (0,1,0)| <= kZone
 static const double kCentreBound = 17.5;   // grid spheres have |c - (0,1,0)| <= this (root box grown by the radius)
 static const double kSlack = 2e-3;         // rasterisation slack (absorbs float error of the walk, ~1e-5)
+static const int32_t kInteriorFlag = 0x40000000;   // in DevAccel::node1: the sphere is interior to its node in x and z
 // 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
 static inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
 // inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
@@ -51,6 +53,14 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
             A.memb_cell[fill[s]++] = (int32_t)k;
             hot_of[s] = ent_hot[e]; in_tree[s] = 1;
         }
+    // level-3 cells: the root box (-11,0,-11)-(11,2,11) (acceleration_structure.h:203) halved three times = 8x8x8 cells of
+    // 2.75 x 0.25 x 2.75; a level-3 node is recognised by holding entries
+    A.cellnode.assign(512, -1);
+    for (size_t k = 0; k < nodes.size(); ++k) {
+        if (nodes[k].count <= 0) continue;
+        const int ix = (int)std::lround((nodes[k].lo[0] + 11.0) / 2.75), iy = (int)std::lround(nodes[k].lo[1] / 0.25), iz = (int)std::lround((nodes[k].lo[2] + 11.0) / 2.75);
+        if (ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) A.cellnode[ix * 64 + iy * 8 + iz] = (int32_t)k;
+    }
     // 2. cell size from the median radius of the tree spheres
     std::vector<double> radii;
     for (int s = 0; s < n_world; ++s) if (in_tree[s]) radii.push_back(std::sqrt((double)hot_of[s].w));
@@ -100,7 +110,16 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         for (int ix = r.ix0; ix <= r.ix1; ++ix)
             for (int iz = r.iz0; iz <= r.iz1; ++iz) {
                 const size_t a = (size_t)fx[(size_t)ix * G + iz]++, b = total + (size_t)fz[(size_t)iz * G + ix]++;
-                const int32_t single = (A.memb_start[(size_t)r.s + 1] - A.memb_start[r.s] == 1) ? A.memb_cell[A.memb_start[r.s]] : -1;
+                int32_t single = (A.memb_start[(size_t)r.s + 1] - A.memb_start[r.s] == 1) ? A.memb_cell[A.memb_start[r.s]] : -1;
+                if (single >= 0) {
+                    // "interior" flag: the float hit point lies within R' of the centre, so if the centre keeps R' + 0.02
+                    // from the node's x and z faces the hit point keeps 0.02 from them — 1000x the rounding error of the
+                    // slab test, whose x and z intervals then surely contain the hit's t (kernel: offer()).
+                    const DevNode& nd = nodes[single];
+                    const float4 g = hot_of[r.s];
+                    const double m = accel_Rp((double)g.w) + 0.02;
+                    if (g.x - m > nd.lo[0] && g.x + m < nd.hix && g.z - m > nd.lo[2] && g.z + m < nd.hiz) single |= kInteriorFlag;
+                }
                 A.hot[a] = hot_of[r.s]; A.id[a] = r.s; A.node1[a] = single;
                 A.hot[b] = hot_of[r.s]; A.id[b] = r.s; A.node1[b] = single;
             }

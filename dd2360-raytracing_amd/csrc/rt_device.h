@@ -48,6 +48,7 @@ struct DevAccel {
     int32_t zoff;
     const int32_t* memb_start; // [n+1] per world-list index: range in memb_cell
     const int32_t* memb_cell;  // pre-order node index (DevNode) of each level-3 node whose buckets hold the sphere
+    const int32_t* cellnode;   // [512] level-3 cell (ix*64 + iy*8 + iz of the root box's 8x8x8 grid) -> pre-order node index, or -1
     int32_t n_large, G;
     float g0, h, inv_h;        // grid origin (same for x and z), cell size
     float ylo, yhi;            // y-slab covering every grid sphere's inflated ball

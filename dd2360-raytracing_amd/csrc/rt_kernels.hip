@@ -246,9 +246,27 @@ RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 // Is the sphere stored in a level-3 node that the reference's traversal visits for this ray?  With no zero direction
 // component a node's slab test passing implies all its ancestors' tests pass (their intervals contain the child's),
 // so the node's own test — the reference's arithmetic — decides.
-RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, int sphere STAT_ARG) {
+RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int sphere STAT_ARG) {
     STAT(st, ST_ELIG, 1);
     const int mb = T.acc.memb_start[sphere], me = T.acc.memb_start[sphere + 1];
+    // Shortcut for spheres stored in many nodes (the big ones): the level-3 cell that contains the hit point.  If the
+    // point keeps 0.012 from all six faces of that cell, the hit's t lies inside all three float slab intervals of the
+    // cell (rounding errors are ~1e-5), so that node's slab test passes; it remains to see that the sphere is stored there.
+    {
+        const float px = r.o.x + cand * r.d.x, py = r.o.y + cand * r.d.y, pz = r.o.z + cand * r.d.z;
+        const int ix = (int)floorf((px + 11.0f) * (1.0f / 2.75f)), iy = (int)floorf(py * 4.0f), iz = (int)floorf((pz + 11.0f) * (1.0f / 2.75f));
+        if (ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) {
+            const int node = T.acc.cellnode[ix * 64 + iy * 8 + iz];
+            if (node >= 0) {
+                const float4 n0 = s_nodes[node * 3 + 0];
+                const float4 n1 = s_nodes[node * 3 + 1];
+                const float m = 0.012f;
+                if (px > n0.x + m && px < n0.w - m && py > n0.y + m && py < n1.x - m && pz > n0.z + m && pz < n1.y - m) {
+                    for (int k = mb; k < me; ++k) if (T.acc.memb_cell[k] == node) return true;
+                }
+            }
+        }
+    }
     for (int k = mb; k < me; ++k) {
         const int node = T.acc.memb_cell[k];
         STAT(st, ST_ELIG_NODES, 1);
@@ -265,12 +283,18 @@ RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float 
     if (cand < best_t) {
         bool ok;
         if (node1 >= 0) {
-            STAT(st, ST_ELIG, 1); STAT(st, ST_ELIG_NODES, 1);
-            const float4 n0 = s_nodes[node1 * 3 + 0];
-            const float4 n1 = s_nodes[node1 * 3 + 1];
-            ok = ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+            STAT(st, ST_ELIG, 1);
+            const int nd = node1 & 0x3fffffff;
+            const float4 n0 = s_nodes[nd * 3 + 0];
+            const float4 n1 = s_nodes[nd * 3 + 1];
+            // Sphere interior to its node in x and z (host flag) and hit point well inside the node in y: the hit's t lies
+            // inside all three float slab intervals (margins 0.02 / 0.012 against rounding errors of ~1e-5), so every
+            // comparison of intersect_ray_aabb comes out "overlap" — the six divisions are not needed to know it passes.
+            const float py = r.o.y + cand * r.d.y;
+            if ((node1 & 0x40000000) && py > n0.y + 0.012f && py < n1.x - 0.012f) ok = true;
+            else { STAT(st, ST_ELIG_NODES, 1); ok = ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y); }
         } else {
-            ok = eligible(T, s_nodes, r, id STAT_PASS);
+            ok = eligible(T, s_nodes, r, cand, id STAT_PASS);
         }
         if (ok) { best_t = cand; best = id; }
     } else if (cand == best_t && id != best && best > 0) {
@@ -419,8 +443,14 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                         id = A.id[e];
                         const int nd = A.node1[e];
                         if (cand < bt) {
-                            if (nd >= 0) { const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1]; elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y); }
-                            else elig = eligible(T, s_nodes, q, id STAT_PASS);
+                            if (nd >= 0) {
+                                const int nn = nd & 0x3fffffff;
+                                const float4 n0 = s_nodes[nn * 3 + 0]; const float4 n1 = s_nodes[nn * 3 + 1];
+                                const float py = q.o.y + cand * q.d.y;
+                                if ((nd & 0x40000000) && py > n0.y + 0.012f && py < n1.x - 0.012f) elig = true;      // see offer()
+                                else elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+                            }
+                            else elig = eligible(T, s_nodes, q, cand, id STAT_PASS);
                         }
                     }
                     // an equal t from a different tree sphere than the current best: the visit order would decide
