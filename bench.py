@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 CONFIGS = {
     "c2": dict(name="C2", nx=1200, ny=800, spp=64, spheres=500, octree=False, spl=30, flops_per_sample=18.2e3),
     "c3": dict(name="C3", nx=1200, ny=800, spp=64, spheres=10000, octree=True, spl=32, flops_per_sample=13.6e3),
+    "c5": dict(name="C5 (one GPU's share: full 4K frame at 32 spp)", nx=3840, ny=2160, spp=32, spheres=100000, octree=True, spl=320, flops_per_sample=78e3),
     "c4": dict(name="C4", nx=1200, ny=800, spp=64, spheres=10000, octree=True, spl=32, flops_per_sample=9.8e3, fp16=True),
 }
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate, spec
