@@ -123,6 +123,8 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
                 A.hot[a] = hot_of[r.s]; A.id[a] = r.s; A.node1[a] = single;
                 A.hot[b] = hot_of[r.s]; A.id[b] = r.s; A.node1[b] = single;
             }
+    // the kernel reads entries in batches and may over-read past a range: pad with entries that can never test positive
+    for (int k = 0; k < 16; ++k) { const float qn = std::nanf(""); A.hot.push_back(make_float4(qn, qn, qn, qn)); A.id.push_back(0); A.node1.push_back(-1); }
     A.cs.resize(2 * (ncell + 1));
     for (size_t c = 0; c <= ncell; ++c) { A.cs[c] = cs_x[c]; A.cs[ncell + 1 + c] = (int32_t)total + cs_z[c]; }
     p.zoff = (int32_t)(ncell + 1);

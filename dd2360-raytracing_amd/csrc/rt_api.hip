@@ -263,7 +263,7 @@ int rt_octree_accel_info(const rt_octree* O, int* grid_dim, float* cell_size, in
     if (!O) return RT_EINVAL;
     if (grid_dim) *grid_dim = O->accel.p.G;
     if (cell_size) *cell_size = O->accel.p.h;
-    if (grid_entries) *grid_entries = (int)(O->accel.id.size() / 2);
+    if (grid_entries) *grid_entries = (int)((O->accel.id.size() - 16) / 2);
     if (large_spheres) *large_spheres = O->accel.p.n_large;
     return 0;
 }

@@ -492,6 +492,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
     int i = W.i, iend = W.iend;
     bool walking = W.walking;
     auto clip_to_hit = [&]() { W.i = i; W.iend = iend; walk_clip(W, A, best_t); i = W.i; iend = W.iend; };
+    const float ra = __builtin_amdgcn_rcpf(a);
     int e = 0, e_end = 0;
     int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
     float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
@@ -530,43 +531,41 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                     if (i != iend) prefetch_col();
                 }
                 if (e < e_end) {
-                    const int last = e_end - 1;
-                    int take = min(RT_BATCH, e_end - e);
-                    STAT(st, ST_TESTS, take);
+                    // RT_BATCH entries per step, loads in flight together.  The loads over-read past e_end (the arrays are
+                    // padded): those entries belong to later cells or are NaN padding, and testing a sphere the walk would
+                    // not have visited cannot change the result (it cannot be a legitimate closer hit) — but only entries
+                    // of this range may be held.
+                    const float4* __restrict__ hp = hot + e;
+                    const int rem = e_end - e;
+                    STAT(st, ST_TESTS, rem < RT_BATCH ? rem : RT_BATCH);
                     float4 s4[RT_BATCH];
 #pragma unroll
-                    for (int k = 0; k < RT_BATCH; ++k) s4[k] = hot[min(e + k, last)];
-                    float bb[RT_BATCH], dd[RT_BATCH];
-                    float dmax = 0.0f;
+                    for (int k = 0; k < RT_BATCH; ++k) s4[k] = hp[k];
+                    // Cheap pre-filter, branch-free for the whole batch: approximate roots (v_sqrt / v_rcp, a few ulp) with
+                    // a margin 400x their error.  A sphere whose far root is surely <= t_min, or whose near root is surely
+                    // beyond the best hit, is rejected by sphere::hit whatever the exact roots are; the first sphere of
+                    // the batch that survives is held for phase B, the entries after it are examined again later.
+                    int kf = RT_BATCH; float bf = 0.0f, df = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < RT_BATCH; ++k) {
+                    for (int k = RT_BATCH - 1; k >= 0; --k) {
                         const float ocx = r.o.x - s4[k].x, ocy = r.o.y - s4[k].y, ocz = r.o.z - s4[k].z;
-                        bb[k] = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+                        const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
                         const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[k].w;
-                        dd[k] = bb[k] * bb[k] - a * c;
-                        dmax = fmaxf(dmax, k < take ? dd[k] : 0.0f);
+                        const float disc = b * b - a * c;
+                        const float sqa = __builtin_amdgcn_sqrtf(disc);
+                        const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
+                        const bool behind = (sqa - b) * ra + m < 0.001f;
+                        const bool beyond = (-b - sqa) * ra - m > best_t;
+                        if (disc > 0.0f && k < rem && !behind && !beyond) { kf = k; bf = b; df = disc; }
                     }
-                    if (dmax > 0.0f) {
-                        const float ra = __builtin_amdgcn_rcpf(a);
-#pragma unroll
-                        for (int k = 0; k < RT_BATCH; ++k) {
-                            if (k < take && dd[k] > 0.0f) {
-                                // Cheap pre-filter: approximate roots (v_sqrt / v_rcp, a few ulp) with a margin 400x their error.
-                                // A sphere whose far root is surely <= t_min, or whose near root is surely beyond the best hit,
-                                // is rejected by sphere::hit whatever the exact roots are; the rest goes to phase B.
-                                const float sqa = __builtin_amdgcn_sqrtf(dd[k]);
-                                const float m = 1e-4f * ((fabsf(bb[k]) + sqa) * ra) + 1e-6f;
-                                const bool behind = (sqa - bb[k]) * ra + m < 0.001f;
-                                const bool beyond = (-bb[k] - sqa) * ra - m > best_t;
-                                if (!behind && !beyond) {
-                                    p_b = bb[k]; p_disc = dd[k]; p_e = e + k; take = k + 1;      // entries after k are re-tested later
-                                    p_id = A.id[e + k]; p_node = A.node1[e + k];                  // in flight until phase B
-                                    STAT(st, ST_DISCPOS, 1);
-                                }
-                            }
-                        }
+                    if (kf < RT_BATCH) {
+                        p_b = bf; p_disc = df; p_e = e + kf;
+                        p_id = A.id[e + kf]; p_node = A.node1[e + kf];                  // in flight until phase B
+                        STAT(st, ST_DISCPOS, 1);
+                        e += kf + 1;
+                    } else {
+                        e += RT_BATCH;
                     }
-                    e += take;
                 } else if (i == iend) {
                     walking = false;
                 }

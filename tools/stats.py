@@ -60,3 +60,6 @@ sp = raw[28:33]
 if sp[4]:
     print("thin waves under load: %.1f k cycles per thin iteration (closest %.1f k); with <= 2 live lanes: %.1f k cycles per iteration (%d iterations)" % (
         sp[0] / sp[4] / 1e3, sp[1] / sp[4] / 1e3, sp[2] / max(1, sp[3]) / 1e3, sp[3]))
+cyc = raw[21:28]
+print("wave-cycles (summed over waves): total %.0fM, closest-hit %.1f%% (fast path %.1f%%, ground %.1f%%, scan %.1f%%), shade+loop %.1f%%" % (
+    cyc[0] / 1e6, 100 * cyc[1] / cyc[0], 100 * cyc[2] / cyc[0], 100 * cyc[3] / cyc[0], 100 * cyc[4] / cyc[0], 100 * cyc[5] / cyc[0]))
