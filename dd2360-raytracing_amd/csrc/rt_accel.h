@@ -23,6 +23,7 @@ struct AccelHost {
     std::vector<int32_t> cs, id, node1; std::vector<float4> hot;     // x-major copy followed by z-major copy
     std::vector<int32_t> memb_start, memb_cell;
     std::vector<int32_t> cellnode;                            // 8x8x8 level-3 cells of the root box -> pre-order node
+    std::vector<int32_t> bits_index; std::vector<uint32_t> cellbits;   // membership bitmaps of the spheres stored in several nodes
     DevAccel p{};
 };
 
@@ -60,6 +61,22 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         if (nodes[k].count <= 0) continue;
         const int ix = (int)std::lround((nodes[k].lo[0] + 11.0) / 2.75), iy = (int)std::lround(nodes[k].lo[1] / 0.25), iz = (int)std::lround((nodes[k].lo[2] + 11.0) / 2.75);
         if (ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) A.cellnode[ix * 64 + iy * 8 + iz] = (int32_t)k;
+    }
+    // membership bitmaps (one 512-bit row per sphere that is stored in more than one node)
+    {
+        std::vector<int> cell_of(nodes.size(), -1);
+        for (int c = 0; c < 512; ++c) if (A.cellnode[c] >= 0) cell_of[A.cellnode[c]] = c;
+        A.bits_index.assign((size_t)n_world, -1);
+        A.cellbits.clear();
+        for (int s = 0; s < n_world; ++s) {
+            const int mb = A.memb_start[s], me = A.memb_start[(size_t)s + 1];
+            if (me - mb < 2) continue;
+            A.bits_index[s] = (int32_t)(A.cellbits.size() / 16);
+            A.cellbits.resize(A.cellbits.size() + 16, 0u);
+            uint32_t* row = &A.cellbits[A.cellbits.size() - 16];
+            for (int k = mb; k < me; ++k) { const int c = cell_of[A.memb_cell[k]]; if (c >= 0) row[c >> 5] |= 1u << (c & 31); }
+        }
+        if (A.cellbits.empty()) A.cellbits.assign(16, 0u);
     }
     // 2. cell size from the median radius of the tree spheres
     std::vector<double> radii;

@@ -48,6 +48,8 @@ struct DevAccel {
     int32_t zoff;
     const int32_t* memb_start; // [n+1] per world-list index: range in memb_cell
     const int32_t* memb_cell;  // pre-order node index (DevNode) of each level-3 node whose buckets hold the sphere
+    const int32_t* bits_index; // [n] per world-list index: row of cellbits for spheres stored in several nodes, else -1
+    const uint32_t* cellbits;  // rows of 16 words: bit (ix*64 + iy*8 + iz) set = the sphere is stored in that level-3 cell
     const int32_t* cellnode;   // [512] level-3 cell (ix*64 + iy*8 + iz of the root box's 8x8x8 grid) -> pre-order node index, or -1
     int32_t n_large, G;
     float g0, h, inv_h;        // grid origin (same for x and z), cell size

@@ -47,6 +47,10 @@ namespace rt {
 #ifndef RT_COOP_MAX
 #define RT_COOP_MAX 4
 #endif
+// phase-A iterations a wave spends on its lanes' walks per bounce iteration before unfinished walks are postponed (0 = no cap)
+#ifndef RT_WALK_CAP
+#define RT_WALK_CAP 0      // measured: capping costs more main-loop iterations than it saves walk steps (cap 2: +32 %, 4: +8 %, 6: +1 %)
+#endif
 // pilot classification: a pixel whose RT_PILOT_SAMPLES pilot samples total at least RT_PILOT_LONG bounces is started as a long chain
 #ifndef RT_PILOT_SAMPLES
 #define RT_PILOT_SAMPLES 2
@@ -68,7 +72,7 @@ namespace rt {
 enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
        ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_LIVE_GE56, ST_LIVE_32, ST_LIVE_8, ST_LIVE_LT8, ST_SWITCHES,
        ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME,
-       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_N };
+       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
@@ -248,25 +252,27 @@ RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 // so the node's own test — the reference's arithmetic — decides.
 RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int sphere STAT_ARG) {
     STAT(st, ST_ELIG, 1);
-    const int mb = T.acc.memb_start[sphere], me = T.acc.memb_start[sphere + 1];
-    // Shortcut for spheres stored in many nodes (the big ones): the level-3 cell that contains the hit point.  If the
+    // Shortcut for spheres stored in several nodes (the big ones): the level-3 cell that contains the hit point.  If the
     // point keeps 0.012 from all six faces of that cell, the hit's t lies inside all three float slab intervals of the
-    // cell (rounding errors are ~1e-5), so that node's slab test passes; it remains to see that the sphere is stored there.
+    // cell (rounding errors are ~1e-5), so that node's slab test passes; it remains to see that the sphere is stored
+    // there (one bit of its membership bitmap).  Two dependent loads instead of a scan of the membership list.
     {
+        const int row = T.acc.bits_index[sphere];
         const float px = r.o.x + cand * r.d.x, py = r.o.y + cand * r.d.y, pz = r.o.z + cand * r.d.z;
         const int ix = (int)floorf((px + 11.0f) * (1.0f / 2.75f)), iy = (int)floorf(py * 4.0f), iz = (int)floorf((pz + 11.0f) * (1.0f / 2.75f));
-        if (ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) {
-            const int node = T.acc.cellnode[ix * 64 + iy * 8 + iz];
-            if (node >= 0) {
+        if (row >= 0 && ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) {
+            const int cell = ix * 64 + iy * 8 + iz;
+            const int node = T.acc.cellnode[cell];
+            const uint32_t word = T.acc.cellbits[row * 16 + (cell >> 5)];
+            if (node >= 0 && ((word >> (cell & 31)) & 1u)) {
                 const float4 n0 = s_nodes[node * 3 + 0];
                 const float4 n1 = s_nodes[node * 3 + 1];
                 const float m = 0.012f;
-                if (px > n0.x + m && px < n0.w - m && py > n0.y + m && py < n1.x - m && pz > n0.z + m && pz < n1.y - m) {
-                    for (int k = mb; k < me; ++k) if (T.acc.memb_cell[k] == node) return true;
-                }
+                if (px > n0.x + m && px < n0.w - m && py > n0.y + m && py < n1.x - m && pz > n0.z + m && pz < n1.y - m) return true;
             }
         }
     }
+    const int mb = T.acc.memb_start[sphere], me = T.acc.memb_start[sphere + 1];
     for (int k = mb; k < me; ++k) {
         const int node = T.acc.memb_cell[k];
         STAT(st, ST_ELIG_NODES, 1);
@@ -478,7 +484,9 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 //   A  every lane steps through its columns / entries (18-op discriminant only) until it holds a sphere with disc > 0;
 //   B  the lanes holding one take the roots (sqrt, divide) and, if it would win, the reference's slab test (eligible()).
 // `tie` is set when the result must be recomputed by the reference scan (exact tie between two tree spheres).
-RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, float& best_t, int& best, bool& tie STAT_ARG) {
+// `budget` > 0: return after that many phase-A iterations even if some lanes have not finished; their position is left
+// in W (W.walking stays true) and the walk is resumed by the next call.
+RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int& e, int& e_end, int budget, float& best_t, int& best, bool& tie STAT_ARG) {
     const DevAccel& A = T.acc;
     const int32_t* __restrict__ cs = A.cs;
     const float4* __restrict__ hot = A.hot;
@@ -493,8 +501,8 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
     bool walking = W.walking;
     auto clip_to_hit = [&]() { W.i = i; W.iend = iend; walk_clip(W, A, best_t); i = W.i; iend = W.iend; };
     const float ra = __builtin_amdgcn_rcpf(a);
-    int e = 0, e_end = 0;
     int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
+    int used = 0;                                            // phase-A iterations of this call (wave-uniform)
     float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
     int p_id = 0, p_node = -1;
     // A thin wave has nothing to hide an L2 round trip behind (~1000 cycles per dependent load), and the frame cannot end
@@ -513,14 +521,16 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
             ne_end = cs[cbase + k1 + 1];
         }
     };
-    if (walking) prefetch_col();
+    if (walking && i != iend) prefetch_col();
     while (true) {
+        if (budget > 0 && used >= budget) break;
         // ---- phase A (wave-uniform loop): lanes without a held sphere take one step per iteration; the wave moves
         //      on to phase B as soon as the holders are numerous enough to make the expensive code worthwhile
         while (true) {
             const bool searching = walking && (p_e < 0);
             const unsigned long long ms = __ballot(searching), mp = __ballot(p_e >= 0);
-            if (ms == 0ull || __popcll(mp) * RT_VOTE_NUM >= __popcll(ms)) break;
+            if (ms == 0ull || __popcll(mp) * RT_VOTE_NUM >= __popcll(ms) || (budget > 0 && used >= budget)) break;
+            ++used;
             STAT(st, ST_A_ITERS_WAVE, 1);
             if (searching) {
                 STAT(st, ST_A_LANE_STEPS, 1);
@@ -595,12 +605,23 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
         p_e = -1;
         }
     }
+    // leave the position behind: next column, end column and the untested rest [e, e_end) of the current column
+    W.i = i; W.iend = iend;
+    W.walking = walking && (e < e_end || i != iend);
+    if (!W.walking) { e = 0; e_end = 0; }
 }
 
 // hitTree (acceleration_structure.h:319-342): ground sphere first, then the tree.
-RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best STAT_ARG) {
-    STAT(st, ST_RAYS, live ? 1 : 0);
-    if (S.ground_valid) {
+// The fast path's per-lane walk is bounded per call (RT_WALK_CAP phase-A iterations): a lane whose walk is not finished
+// comes back with ts.pending set and resumes on the next call with the same ray, while the lanes that are done go on to
+// shade and start new rays — the wave no longer waits for its longest walk.  `closest`/`best` persist with the caller.
+struct TreeState { Walk W; int e, e_end; float g_t; int g_id; bool tie, pending; };
+
+RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best, TreeState& ts STAT_ARG) {
+    const bool fresh = live && !ts.pending;
+    STAT(st, ST_RAYS, fresh ? 1 : 0);
+    if (fresh) { closest = FLT_MAX; best = -1; }
+    if (S.ground_valid && fresh) {
         const float4 g = S.list_hot[0];
         int gb = -1;
         sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
@@ -609,28 +630,55 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
 #ifdef RT_STATS
     const unsigned long long tG = TICK(); st.cyc[4] += tG;      // (entry stamp is subtracted by the caller's tC0)
 #endif
-    bool slow = live;
+    bool slow = fresh;
     if (T.acc.enabled) {
         // preconditions of the exactness argument; any NaN/inf makes a comparison false and sends the ray to the scan
         const float zx = r.o.x, zy = r.o.y - 1.0f, zz = r.o.z;
-        const bool fast = live && (a >= 9.094947e-13f) && (a <= 1.0995116e12f) && (r.d.x != 0.0f) && (r.d.z != 0.0f)
+        const bool fast = fresh && (a >= 9.094947e-13f) && (a <= 1.0995116e12f) && (r.d.x != 0.0f) && (r.d.z != 0.0f)
                           && (fabsf(r.d.y) >= 9.094947e-13f) && (zx * zx + zy * zy + zz * zz <= T.acc.zone2);
-        slow = live && !fast;
+        slow = fresh && !fast;
         STAT(st, ST_FAST, fast ? 1 : 0); STAT(st, ST_SLOW, slow ? 1 : 0);
-        const float g_t = closest; const int g_id = best;
-        bool tie = false;
-        Walk W; W.walking = false; W.i = 0; W.iend = 0; W.coff = 0; W.om_c = 0.f; W.on_c = 0.f; W.slope = 0.f; W.dm_c = 0.f; W.fwd = true;
         if (fast) {
+            ts.g_t = closest; ts.g_id = best; ts.tie = false;
+            const float ra = __builtin_amdgcn_rcpf(a);
             for (int k = 0; k < T.acc.n_large; ++k) {
-                const float cand = sphere_candidate(r, a, T.acc.large_hot[k]);
-                offer(T, s_nodes, r, cand, T.acc.large_id[k], -1, closest, best, tie STAT_PASS);
+                // same cheap pre-filter as in the walk: exact roots only for a sphere that can still win
+                const float4 sp = T.acc.large_hot[k];
+                const float ocx = r.o.x - sp.x, ocy = r.o.y - sp.y, ocz = r.o.z - sp.z;
+                const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
+                const float disc = b * b - a * c;
+                if (disc > 0.0f) {
+                    const float sqa = __builtin_amdgcn_sqrtf(disc);
+                    const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
+                    const bool behind = (sqa - b) * ra + m < 0.001f;
+                    const bool beyond = (-b - sqa) * ra - m > closest;
+                    if (!behind && !beyond) {
+                        const float sq = sqrtf(disc);
+                        float cand = __builtin_inff();
+                        const float t1 = (-b - sq) / a;
+                        if (t1 > 0.001f) cand = t1;
+                        else { const float t2 = (-b + sq) / a; if (t2 > 0.001f) cand = t2; }
+                        offer(T, s_nodes, r, cand, T.acc.large_id[k], -1, closest, best, ts.tie STAT_PASS);
+                    }
+                }
             }
-            W = walk_setup(T.acc, r, closest, best);
+            ts.W = walk_setup(T.acc, r, closest, best);
+            ts.e = 0; ts.e_end = 0;
         }
-        const int nf = __popcll(__ballot(fast));
-        if (nf > 0 && nf <= RT_COOP_MAX) walk_coop(T, s_nodes, r, a, W, fast, closest, best, tie STAT_PASS);
-        else if (fast) walk_lanes(T, s_nodes, r, a, W, closest, best, tie STAT_PASS);
-        if (fast && tie) { closest = g_t; best = g_id; slow = true; STAT(st, ST_TIE, 1); }
+#ifdef RT_STATS
+        const unsigned long long tL = TICK(); st.cyc[5] += tL - tG;       // large spheres + walk set-up
+#endif
+        const bool walker = fast || (live && ts.pending);
+        const int nw = __popcll(__ballot(walker));
+        // the cooperative walk starts at a column boundary: not while a lane has a partly tested column
+        const bool coop = nw > 0 && nw <= RT_COOP_MAX && __ballot(walker && ts.e < ts.e_end) == 0ull;
+        if (coop) walk_coop(T, s_nodes, r, a, ts.W, walker, closest, best, ts.tie STAT_PASS);
+        else if (walker) walk_lanes(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
+        if (walker) {
+            ts.pending = ts.W.walking;
+            if (!ts.pending && ts.tie) { closest = ts.g_t; best = ts.g_id; slow = true; STAT(st, ST_TIE, 1); }
+        }
     }
 #ifdef RT_STATS
     const unsigned long long tS0 = TICK(); st.cyc[1] += tS0 - tG;     // fast path (large spheres + setup + walk), wave time
@@ -903,6 +951,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     else { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
 
     const unsigned int thin_cap = (unsigned int)(n_waves / 4);
+    float closest = FLT_MAX; int best = -1;
+    TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
+    ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
     while (true) {
         // ---- wave-level bookkeeping (uniform)
         const unsigned long long m_live = __ballot(live);
@@ -936,17 +987,17 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         { const int nl = __popcll(__ballot(live)); STAT(st, nl >= 56 ? ST_LIVE_GE56 : nl >= 32 ? ST_LIVE_32 : nl >= 8 ? ST_LIVE_8 : ST_LIVE_LT8, 1); }
 #endif
         const float a = dot3(r.d, r.d);
-        float closest = FLT_MAX; int best = -1;
+        if (!TREE) { closest = FLT_MAX; best = -1; }
 #ifdef RT_STATS
         const unsigned long long tC0 = TICK();
 #endif
-        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
 #ifdef RT_STATS
         const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0; if (thin) dbg_thin_closest += tC1 - tC0;
         if (live) { ++pix_iters; }
 #endif
-        if (live) {
+        if (live && !(TREE && ts.pending)) {
             ++iters;
             bool done;                                     // this sample's path has ended
             if (best >= 0) {
@@ -1005,7 +1056,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         const unsigned long long tot = TICK() - tK0;
         atomicAdd(&g_stats[ST_CYC_TOTAL], tot);
         atomicAdd(&g_stats[ST_CYC_CLOSEST], st.cyc[0]); atomicAdd(&g_stats[ST_CYC_WALK_A], st.cyc[1]); atomicAdd(&g_stats[ST_CYC_WALK_B], st.cyc[4] - st.cyc[2]);
-        atomicAdd(&g_stats[ST_CYC_SCAN], st.cyc[3]); atomicAdd(&g_stats[ST_CYC_SHADE], tot - st.cyc[0]);
+        atomicAdd(&g_stats[ST_CYC_SCAN], st.cyc[3]); atomicAdd(&g_stats[ST_CYC_SHADE], tot - st.cyc[0]); atomicAdd(&g_stats[ST_SPARE4 + 1], st.cyc[5]);
         atomicAdd(&g_stats[ST_REALTIME], __builtin_amdgcn_s_memrealtime() - rK0);
     }
 #endif
@@ -1049,12 +1100,15 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
 #endif
+    float closest = FLT_MAX; int best = -1;
+    TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
+    ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
     while (__ballot(live) != 0ull) {
         const float a = dot3(r.d, r.d);
-        float closest = FLT_MAX; int best = -1;
-        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best STAT_PASS);
+        if (!TREE) { closest = FLT_MAX; best = -1; }
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
-        if (live) {
+        if (live && !(TREE && ts.pending)) {
             ++bounces; ++depth;
             bool done = true;
             if (best >= 0) { const bool cont = scatter(A.scene, best, closest, r, att, ps); done = !cont || depth >= 50; }
@@ -1131,8 +1185,12 @@ __global__ __launch_bounds__(256) void k_trace(DevScene S, DevTree T, const floa
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
 #endif
-    if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best STAT_PASS);
-    else closest_list(S, r, a, live, closest, best);
+    if (TREE) {
+        TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
+        ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
+        bool act = live;
+        do { closest_tree(S, T, s_nodes, r, a, act, closest, best, ts STAT_PASS); act = live && ts.pending; } while (__ballot(act) != 0ull);
+    } else closest_list(S, r, a, live, closest, best);
     if (!live) return;
     rt_hit_record h;
     h.sphere = best; h.t = 0.f; h.p[0] = h.p[1] = h.p[2] = 0.f; h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
