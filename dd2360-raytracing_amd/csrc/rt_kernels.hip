@@ -72,7 +72,7 @@ namespace rt {
 enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
        ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_LIVE_GE56, ST_LIVE_32, ST_LIVE_8, ST_LIVE_LT8, ST_SWITCHES,
        ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME,
-       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_N };
+       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_SPARE6, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
@@ -581,6 +581,9 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                 }
             }
         }
+#ifdef RT_STATS
+        const unsigned long long tB0 = TICK();
+#endif
         if (__ballot(p_e >= 0) == 0ull) break;                 // nobody holds a sphere and nobody is searching
         STAT(st, ST_B_ROUNDS_WAVE, 1);
         if (p_e >= 0) {
@@ -604,6 +607,9 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
         }
         p_e = -1;
         }
+#ifdef RT_STATS
+        st.cyc[6] += TICK() - tB0;
+#endif
     }
     // leave the position behind: next column, end column and the untested rest [e, e_end) of the current column
     W.i = i; W.iend = iend;
@@ -1056,7 +1062,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         const unsigned long long tot = TICK() - tK0;
         atomicAdd(&g_stats[ST_CYC_TOTAL], tot);
         atomicAdd(&g_stats[ST_CYC_CLOSEST], st.cyc[0]); atomicAdd(&g_stats[ST_CYC_WALK_A], st.cyc[1]); atomicAdd(&g_stats[ST_CYC_WALK_B], st.cyc[4] - st.cyc[2]);
-        atomicAdd(&g_stats[ST_CYC_SCAN], st.cyc[3]); atomicAdd(&g_stats[ST_CYC_SHADE], tot - st.cyc[0]); atomicAdd(&g_stats[ST_SPARE4 + 1], st.cyc[5]);
+        atomicAdd(&g_stats[ST_CYC_SCAN], st.cyc[3]); atomicAdd(&g_stats[ST_CYC_SHADE], tot - st.cyc[0]); atomicAdd(&g_stats[ST_SPARE4 + 1], st.cyc[5]); atomicAdd(&g_stats[ST_SPARE4 + 2], st.cyc[6]);
         atomicAdd(&g_stats[ST_REALTIME], __builtin_amdgcn_s_memrealtime() - rK0);
     }
 #endif

@@ -64,3 +64,4 @@ cyc = raw[21:28]
 print("wave-cycles (summed over waves): total %.0fM, closest-hit %.1f%% (fast path %.1f%%, ground %.1f%%, scan %.1f%%), shade+loop %.1f%%" % (
     cyc[0] / 1e6, 100 * cyc[1] / cyc[0], 100 * cyc[2] / cyc[0], 100 * cyc[3] / cyc[0], 100 * cyc[4] / cyc[0], 100 * cyc[5] / cyc[0]))
 print("  inside the fast path: large spheres + set-up %.1f%% of total wave-cycles" % (100 * raw[33] / cyc[0]))
+print("  phase B (roots + offer) of the per-lane walk: %.1f%% of total wave-cycles" % (100 * raw[34] / cyc[0]))
