@@ -420,3 +420,33 @@ def test_arbitrary_world_hit_records_and_frames(rt, cuda, seed, n, spl):
     ref, ref_st = S_tree.render(ns, nthreads=8)
     assert np.array_equal(bits(fb.cpu().numpy().reshape(ny, nx, 3)), bits(ref))
     assert np.array_equal(st.cpu().numpy().view(np.uint32).reshape(-1, 12)[:, :6], ref_st[:, :6])
+
+
+# ---------------------------------------------------------------------------------------------------- host program
+@pytest.mark.parametrize("args,n,nx,ny,ns,tree,spl", [
+    (["3", "500", "64", "40", "4", "1", "30"], 500, 64, 40, 4, True, 30),
+    (["3", "22", "100", "56", "3", "0", "30"], 22, 100, 56, 3, False, 30),
+])
+def test_rt_main_host_program_writes_the_oracle_ppm(rt, cuda, tmp_path, args, n, nx, ny, ns, tree, spl):
+    """rt_main (host/main.cpp, the counterpart of the reference's main(), main.cu:347-477) in output mode 3: the
+    output.ppm it writes through the C-ABI equals the oracle's PPM byte for byte; stderr carries the reference's lines."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dd2360-raytracing_amd", "rt_main")
+    p = subprocess.run([exe] + args, cwd=tmp_path, capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    err = p.stderr.decode()
+    assert "Rendering a %dx%d image with %d samples per pixel in 8x8 blocks." % (nx, ny, ns) in err
+    assert "Number of spheres: %d" % n in err and ("Use octree: ON" if tree else "Use octree: OFF") in err and "took " in err
+    ref, _ = OracleScene(n, nx, ny, use_octree=tree, spl=spl).render(ns, nthreads=8)
+    assert (tmp_path / "output.ppm").read_bytes() == ppm_bytes(ref)
+
+
+def test_rt_main_error_convention(rt, cuda, tmp_path):
+    """checkCudaErrors convention (main.cu:27-37): a failing call prints '... error = <code> at <file>:<line> ...' and exits 99."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dd2360-raytracing_amd", "rt_main")
+    p = subprocess.run([exe, "1", "3", "64", "40", "2"], cwd=tmp_path, capture_output=True, timeout=120)   # NUM_SPHERES must be > 4
+    assert p.returncode == 99
+    assert "error = " in p.stderr.decode() and "main.cpp" in p.stderr.decode()
