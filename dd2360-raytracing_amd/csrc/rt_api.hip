@@ -441,4 +441,36 @@ int rt_write_ppm(const char* path, int nx, int ny, const void* fb, int precision
     return w == buf.size() ? 0 : RT_EIO;
 }
 
+int rt_write_image(const char* path, int nx, int ny, const void* fb, int precision, int format) {
+    if (!path || nx <= 0 || ny <= 0 || !fb) return RT_EINVAL;
+    if (precision != RT_PRECISION_FP32 && precision != RT_PRECISION_FP16) return RT_EINVAL;
+    if (format == RT_IMAGE_P3) return rt_write_ppm(path, nx, ny, fb, precision);
+    if (format != RT_IMAGE_P6 && format != RT_IMAGE_PFM) return RT_EINVAL;
+    FILE* f = fopen(path, "wb");
+    if (!f) return RT_EIO;
+    bool ok = true;
+    try {
+        if (format == RT_IMAGE_P6) {
+            ok = fprintf(f, "P6\n%d %d\n255\n", nx, ny) > 0;
+            std::vector<unsigned char> row((size_t)nx * 3);
+            for (int j = ny - 1; j >= 0 && ok; j--) {
+                for (int i = 0; i < nx * 3; i++) {
+                    const int v = static_cast<int>(255.99 * channel(fb, (size_t)j * nx * 3 + i, precision));
+                    row[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                }
+                ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+            }
+        } else {
+            ok = fprintf(f, "PF\n%d %d\n-1.0\n", nx, ny) > 0;
+            std::vector<float> row((size_t)nx * 3);
+            for (int j = 0; j < ny && ok; j++) {
+                for (int i = 0; i < nx * 3; i++) row[i] = channel(fb, (size_t)j * nx * 3 + i, precision);
+                ok = fwrite(row.data(), sizeof(float), row.size(), f) == row.size();
+            }
+        }
+    } catch (const std::bad_alloc&) { fclose(f); return RT_ENOMEM; }
+    if (fclose(f) != 0) ok = false;
+    return ok ? 0 : RT_EIO;
+}
+
 } // extern "C"

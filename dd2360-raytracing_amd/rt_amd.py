@@ -15,6 +15,7 @@ FP32, FP16 = 0, 1
 MAT_NONE, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = -1, 0, 1, 2
 OCTREE_MAX_NODES = 585
 TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
+IMAGE_P3, IMAGE_P6, IMAGE_PFM = 0, 1, 2
 
 # PODs of include/rt_amd.h
 rand_state_dtype = np.dtype([("d", "<u4"), ("v", "<u4", 5), ("boxmuller_flag", "<i4"), ("boxmuller_flag_double", "<i4"),
@@ -67,6 +68,7 @@ SYMBOLS = {
     "rt_trace_rays": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _i, _i, _vp, _i]),
     "rt_format_ppm": (_i64, [_i, _i, _vp, _i, _vp, _i64]),
+    "rt_write_image": (_i, [C.c_char_p, _i, _i, _vp, _i, _i]),
 }
 
 _LIB = None
@@ -268,6 +270,11 @@ def assemble(fb_full, fb_parts, max_x, max_y, nparts, precision=FP32):
 
 def trace_rays(world, octree, d_rays, n, d_out):
     check(lib().rt_trace_rays(world.h, octree.h if octree is not None else None, _dev(d_rays), n, _dev(d_out), _stream()), "rt_trace_rays")
+
+
+def write_image(path, fb_host, nx, ny, precision=FP32, fmt=IMAGE_P6):
+    fb_host = np.ascontiguousarray(fb_host)
+    check(lib().rt_write_image(str(path).encode(), nx, ny, _np(fb_host), precision, fmt), "rt_write_image")
 
 
 def format_ppm(fb_host, nx, ny, precision=FP32):

@@ -174,6 +174,15 @@ int rt_write_ppm(const char* path, int nx, int ny, const void* fb, int precision
 /* same bytes into memory; returns the length, or the required length when cap is too small / out is NULL */
 int64_t rt_format_ppm(int nx, int ny, const void* fb, int precision, char* out, int64_t cap);
 
+/* Binary companions of the ASCII P3 writer (at 4K the P3 text is ~100 MB and dominates end-to-end time).
+ * RT_IMAGE_P6: "P6" binary PPM, same quantisation as main.cu:327-329 (int(255.99*c), clamped to 0..255), top row first.
+ * RT_IMAGE_PFM: "PF" float image, little-endian (-1.0 scale), bottom row first (the framebuffer's own row order), the
+ * gamma-corrected channel values unquantised.  fb is a HOST buffer in the framebuffer layout of rt_render. */
+#define RT_IMAGE_P3 0
+#define RT_IMAGE_P6 1
+#define RT_IMAGE_PFM 2
+int rt_write_image(const char* path, int nx, int ny, const void* fb, int precision, int format);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,31 @@ def test_reference_host_program_builds():
     if not os.path.exists(os.path.join(ROOT, "dd2360-raytracing_amd", "rt_main")):
         __graft_entry__.build()
     assert os.access(os.path.join(ROOT, "dd2360-raytracing_amd", "rt_main"), os.X_OK)
+
+
+def test_binary_image_writers(rt, tmp_path):
+    """P6 and PFM companions of the P3 writer: same quantisation / row order rules, checked against numpy."""
+    rng = np.random.default_rng(2)
+    fb = rng.uniform(0, 1, (7, 11, 3)).astype(np.float32)
+    fb[3, 4] = [0.0, 1.0, 0.5]
+    p6 = tmp_path / "a.ppm"
+    rt.write_image(p6, fb, 11, 7, fmt=rt.IMAGE_P6)
+    raw = p6.read_bytes()
+    head = b"P6\n11 7\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 7 * 11 * 3
+    want = np.clip((255.99 * fb[::-1].astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(7, 11, 3), want)
+    # the P6 bytes are the P3 numbers
+    p3 = [int(x) for x in rt.format_ppm(fb, 11, 7).split()[4:]]
+    assert p3 == want.ravel().tolist()
+    pf = tmp_path / "a.pfm"
+    rt.write_image(pf, fb, 11, 7, fmt=rt.IMAGE_PFM)
+    raw = pf.read_bytes()
+    head = b"PF\n11 7\n-1.0\n"
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(7, 11, 3).view(np.uint32), fb.view(np.uint32))
+    # fp16 framebuffers go through the same writers
+    rt.write_image(tmp_path / "h.pfm", fb.astype(np.float16), 11, 7, precision=rt.FP16, fmt=rt.IMAGE_PFM)
+    raw = (tmp_path / "h.pfm").read_bytes()
+    assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(7, 11, 3), fb.astype(np.float16).astype(np.float32))
+    assert rt.lib().rt_write_image(b"/nonexistent_dir/x.ppm", 11, 7, fb.ctypes.data, 0, 1) == -3
