@@ -44,6 +44,8 @@ struct rt_world {
     // queued on different streams never share one
     unsigned int* d_queue = nullptr; unsigned launches = 0;
     // scheduling workspace of rt_render (tile costs and hand-out order), grown on demand
+    // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_world_render_times
+    hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
     int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
 };
 static const unsigned kQueueSlots = 64, kQueueStride = 16;
@@ -182,6 +184,7 @@ int rt_free_world(rt_world* W) {
     int rc = 0;
     void* bufs[10] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue, W->d_cost, W->d_order, W->d_flags, W->d_long};
     for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
+    if (W->ev_ready) for (int k = 0; k < 64; ++k) { (void)hipEventDestroy(W->ev0[k]); (void)hipEventDestroy(W->ev1[k]); }
     delete W;
     return rc;
 }
@@ -342,7 +345,18 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
-    if (world->precision == RT_PRECISION_FP16) return (int)launch_render_h(A, d_octree != nullptr, mode, (hipStream_t)stream);
+    if (!wm->ev_ready) {
+        for (int k = 0; k < 64; ++k) { RT_TRY(hipEventCreate(&wm->ev0[k])); RT_TRY(hipEventCreate(&wm->ev1[k])); }
+        wm->ev_ready = true;
+    }
+    const unsigned ek = wm->ev_head % 64u;
+    if (world->precision == RT_PRECISION_FP16) {
+        RT_TRY(hipEventRecord(wm->ev0[ek], (hipStream_t)stream));
+        RT_TRY(launch_render_h(A, d_octree != nullptr, mode, (hipStream_t)stream));
+        RT_TRY(hipEventRecord(wm->ev1[ek], (hipStream_t)stream));
+        wm->ev_head++; if (wm->ev_count < 64) wm->ev_count++;
+        return 0;
+    }
     if (mode == 0 && ns >= 4) {
         // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame:
         // call rt_render once before capturing it into a hipGraph.
@@ -363,7 +377,27 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
         A.order = wm->d_order;
         if (classify) { A.long_flag = wm->d_flags; A.long_list = wm->d_long; }
     }
-    return (int)launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream);
+    RT_TRY(hipEventRecord(wm->ev0[ek], (hipStream_t)stream));
+    RT_TRY(launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream));
+    RT_TRY(hipEventRecord(wm->ev1[ek], (hipStream_t)stream));
+    wm->ev_head++; if (wm->ev_count < 64) wm->ev_count++;
+    return 0;
+}
+
+int rt_world_render_times(rt_world* W, float* ms_out, int max, int* count) {
+    if (!W || !ms_out || !count || max < 0) return RT_EINVAL;
+    int n = 0;
+    const unsigned have = W->ev_count;
+    for (unsigned k = 0; k < have && n < max; ++k) {
+        const unsigned slot = (W->ev_head - have + k) % 64u;
+        RT_TRY(hipEventSynchronize(W->ev1[slot]));
+        float ms = 0.f;
+        RT_TRY(hipEventElapsedTime(&ms, W->ev0[slot], W->ev1[slot]));
+        ms_out[n++] = ms;
+    }
+    *count = n;
+    W->ev_count = 0;
+    return 0;
 }
 
 int rt_render(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {

@@ -64,6 +64,7 @@ SYMBOLS = {
     "rt_render_init": (_i, [_i, _i, _vp, Partition, _vp]),
     "rt_render": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
     "rt_render_progressive": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
+    "rt_world_render_times": (_i, [_vp, _vp, _i, _vp]),
     "rt_assemble": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rt_trace_rays": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _i, _i, _vp, _i]),
@@ -160,6 +161,13 @@ class World:
     def upload(self):
         check(lib().rt_world_upload(self.h), "rt_world_upload")
         return self
+
+    def render_times(self):
+        """device times (ms) of the render kernel of the calls since the last query (HIP events on the launch stream)"""
+        out = np.zeros(64, np.float32)
+        n = C.c_int(0)
+        check(lib().rt_world_render_times(self.h, _np(out), 64, C.byref(n)), "rt_world_render_times")
+        return out[: n.value].tolist()
 
     def close(self):
         if getattr(self, "h", None):

@@ -158,6 +158,12 @@ int rt_render(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_
 int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, const rt_world* world,
                           rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream);
 
+/* Device time of the dominant kernel (k_render / k_render_h) of the most recent rt_render / rt_render_progressive calls on
+ * this world: HIP events recorded on the launch stream directly around that kernel (the scheduling pre-pass of rt_render
+ * is outside).  Copies up to `max` durations (milliseconds, oldest first, at most the last 64 launches) into ms_out,
+ * stores how many in *count, and forgets them.  Synchronises with the recorded events. */
+int rt_world_render_times(rt_world* world, float* ms_out, int max, int* count);
+
 /* Reassemble a full row-major frame from nparts tile-major part buffers laid out back to back, each padded to
  * rt_part_pixels(max_x,max_y,{0,nparts}) elements (the layout an all-gather of the parts produces). */
 int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream);
