@@ -450,3 +450,22 @@ def test_rt_main_error_convention(rt, cuda, tmp_path):
     p = subprocess.run([exe, "1", "3", "64", "40", "2"], cwd=tmp_path, capture_output=True, timeout=120)   # NUM_SPHERES must be > 4
     assert p.returncode == 99
     assert "error = " in p.stderr.decode() and "main.cpp" in p.stderr.decode()
+
+
+def test_reference_default_configuration(rt, cuda):
+    """The reference's own compile-time defaults (main.cu:22-24, :348-350; acceleration_structure.h:15): 1200x800, ns = 10,
+    NUM_SPHERES 8000, SPHERE_RADIUS 0.1, USE_OCTREE, SPHERES_PER_LEAF 30 — sampled rows against the oracle, both traversals equal."""
+    torch = cuda
+    nx, ny, ns, n, spl = 1200, 800, 10, 8000, 30
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, spl)
+    assert O.info()["dropped_full"] == 0 and W.created == 8000
+    fb, st = gpu_render(rt, torch, W, O, nx, ny, ns)
+    O.set_traversal(rt.TRAVERSAL_REFERENCE)
+    fb2, st2 = gpu_render(rt, torch, W, O, nx, ny, ns)
+    assert torch.equal(fb.view(torch.int32), fb2.view(torch.int32)) and torch.equal(st, st2)
+    got = fb.cpu().numpy().reshape(ny, nx, 3)
+    S = OracleScene(n, nx, ny, use_octree=True, spl=spl)
+    for row in (0, 127, 402, 640, 799):
+        ref, _ = S.render(ns, row0=row, rows=1, nthreads=1)
+        assert np.array_equal(bits(got[row]), bits(ref[0])), "row %d" % row
