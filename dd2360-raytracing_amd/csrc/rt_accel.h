@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <limits>
 #include "rt_device.h"
 
 namespace rt {
@@ -21,6 +23,7 @@ namespace rt {
 struct AccelHost {
     std::vector<float4> large_hot; std::vector<int32_t> large_id;
     std::vector<int32_t> cs, id, node1; std::vector<float4> hot;     // x-major copy followed by z-major copy
+    std::vector<float4> brick, large_brick;                           // per entry: two float4 (DevAccel::brick)
     std::vector<int32_t> memb_start, memb_cell;
     std::vector<int32_t> cellnode;                            // 8x8x8 level-3 cells of the root box -> pre-order node
     std::vector<int32_t> bits_index; std::vector<uint32_t> cellbits;   // membership bitmaps of the spheres stored in several nodes
@@ -31,7 +34,11 @@ struct AccelHost {
 static const double kZone = 24.0;          // near zone: |o - (0,1,0)| <= kZone
 static const double kCentreBound = 17.5;   // grid spheres have |c - (0,1,0)| <= this (root box grown by the radius)
 static const double kSlack = 2e-3;         // rasterisation slack (absorbs float error of the walk, ~1e-5)
-static const int32_t kInteriorFlag = 0x40000000;   // in DevAccel::node1: the sphere is interior to its node in x and z
+// "brick" of a sphere = the box of level-3 cells [ix0..ix1] x [iy0..iy1] x [iz0..iz1] when EVERY cell of that box stores the
+// sphere.  A hit point that keeps 0.012 from the brick's six outer faces lies in a stored cell whose slab test passes
+// (DESIGN.md App. A.3).  The margins below are 0.012 in cell units (cells are 2.75 x 0.25 x 2.75) plus >= 5e-4 of distance
+// for the rounding of the cell coordinates.
+static const double kBrickMxz = 0.0046, kBrickMy = 0.05;
 // 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
 static inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
 // inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
@@ -78,6 +85,35 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         }
         if (A.cellbits.empty()) A.cellbits.assign(16, 0u);
     }
+    // bricks: cell-coordinate bounds (margins included) of the spheres whose storing cells form a complete box
+    std::vector<float4> sb_lo((size_t)n_world), sb_hi((size_t)n_world);
+    {
+        std::vector<int> cell_of(nodes.size(), -1);
+        for (int c = 0; c < 512; ++c) if (A.cellnode[c] >= 0) cell_of[A.cellnode[c]] = c;
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int s = 0; s < n_world; ++s) {
+            const int mb = A.memb_start[s], me = A.memb_start[(size_t)s + 1];
+            int lo[3] = {8, 8, 8}, hi[3] = {-1, -1, -1};
+            bool ok = me > mb;
+            for (int k = mb; k < me && ok; ++k) {
+                const int c = cell_of[A.memb_cell[k]];
+                if (c < 0) { ok = false; break; }
+                const int q[3] = {c >> 6, (c >> 3) & 7, c & 7};
+                for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], q[d]); hi[d] = std::max(hi[d], q[d]); }
+            }
+            // distinct nodes map to distinct cells, so "as many nodes as the box has cells" = every cell of the box stores it
+            if (ok) ok = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) == me - mb;
+            const int32_t single = (me - mb == 1) ? A.memb_cell[mb] : -1;
+            float idbits, nodebits;
+            { const int32_t v = s; std::memcpy(&idbits, &v, 4); std::memcpy(&nodebits, &single, 4); }
+            if (ok) {
+                sb_lo[s] = make_float4((float)(lo[0] + kBrickMxz), (float)(lo[1] + kBrickMy), (float)(lo[2] + kBrickMxz), idbits);
+                sb_hi[s] = make_float4((float)(hi[0] + 1 - kBrickMxz), (float)(hi[1] + 1 - kBrickMy), (float)(hi[2] + 1 - kBrickMxz), nodebits);
+            } else {
+                sb_lo[s] = make_float4(inf, inf, inf, idbits); sb_hi[s] = make_float4(-inf, -inf, -inf, nodebits);
+            }
+        }
+    }
     // 2. cell size from the median radius of the tree spheres
     std::vector<double> radii;
     for (int s = 0; s < n_world; ++s) if (in_tree[s]) radii.push_back(std::sqrt((double)hot_of[s].w));
@@ -103,7 +139,10 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         const double Rp = accel_Rp((double)g.w);
         const double dc = std::sqrt((double)g.x * g.x + ((double)g.y - 1.0) * ((double)g.y - 1.0) + (double)g.z * g.z);
         const bool inside = (g.x - Rp > g0 + h) && (g.x + Rp < g0 + (G - 1) * h) && (g.z - Rp > g0 + h) && (g.z + Rp < g0 + (G - 1) * h);
-        if (Rp > Rlim || dc > kCentreBound || !inside || !(g.w >= 0.0f)) { A.large_hot.push_back(g); A.large_id.push_back(s); continue; }
+        if (Rp > Rlim || dc > kCentreBound || !inside || !(g.w >= 0.0f)) {
+            A.large_hot.push_back(g); A.large_id.push_back(s); A.large_brick.push_back(sb_lo[s]); A.large_brick.push_back(sb_hi[s]);
+            continue;
+        }
         Reg r; r.s = s;
         r.ix0 = (int)std::floor((g.x - Rp - g0) / h - 1e-4); r.ix1 = (int)std::floor((g.x + Rp - g0) / h + 1e-4);
         r.iz0 = (int)std::floor((g.z - Rp - g0) / h - 1e-4); r.iz1 = (int)std::floor((g.z + Rp - g0) / h + 1e-4);
@@ -122,26 +161,19 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     A.hot.assign(2 * total, make_float4(0, 0, 0, 0));
     A.id.assign(2 * total, 0);
     A.node1.assign(2 * total, -1);
+    A.brick.assign(4 * total, make_float4(0, 0, 0, 0));
     std::vector<int32_t> fx(cs_x.begin(), cs_x.end() - 1), fz(cs_z.begin(), cs_z.end() - 1);
     for (const Reg& r : regs)
         for (int ix = r.ix0; ix <= r.ix1; ++ix)
             for (int iz = r.iz0; iz <= r.iz1; ++iz) {
                 const size_t a = (size_t)fx[(size_t)ix * G + iz]++, b = total + (size_t)fz[(size_t)iz * G + ix]++;
-                int32_t single = (A.memb_start[(size_t)r.s + 1] - A.memb_start[r.s] == 1) ? A.memb_cell[A.memb_start[r.s]] : -1;
-                if (single >= 0) {
-                    // "interior" flag: the float hit point lies within R' of the centre, so if the centre keeps R' + 0.02
-                    // from the node's x and z faces the hit point keeps 0.02 from them — 1000x the rounding error of the
-                    // slab test, whose x and z intervals then surely contain the hit's t (kernel: offer()).
-                    const DevNode& nd = nodes[single];
-                    const float4 g = hot_of[r.s];
-                    const double m = accel_Rp((double)g.w) + 0.02;
-                    if (g.x - m > nd.lo[0] && g.x + m < nd.hix && g.z - m > nd.lo[2] && g.z + m < nd.hiz) single |= kInteriorFlag;
-                }
-                A.hot[a] = hot_of[r.s]; A.id[a] = r.s; A.node1[a] = single;
-                A.hot[b] = hot_of[r.s]; A.id[b] = r.s; A.node1[b] = single;
+                const int32_t single = (A.memb_start[(size_t)r.s + 1] - A.memb_start[r.s] == 1) ? A.memb_cell[A.memb_start[r.s]] : -1;
+                A.hot[a] = hot_of[r.s]; A.id[a] = r.s; A.node1[a] = single; A.brick[2 * a] = sb_lo[r.s]; A.brick[2 * a + 1] = sb_hi[r.s];
+                A.hot[b] = hot_of[r.s]; A.id[b] = r.s; A.node1[b] = single; A.brick[2 * b] = sb_lo[r.s]; A.brick[2 * b + 1] = sb_hi[r.s];
             }
     // the kernel reads entries in batches and may over-read past a range: pad with entries that can never test positive
-    for (int k = 0; k < 16; ++k) { const float qn = std::nanf(""); A.hot.push_back(make_float4(qn, qn, qn, qn)); A.id.push_back(0); A.node1.push_back(-1); }
+    for (int k = 0; k < 16; ++k) { const float qn = std::nanf(""); A.hot.push_back(make_float4(qn, qn, qn, qn)); A.id.push_back(0); A.node1.push_back(-1); A.brick.push_back(make_float4(qn, qn, qn, 0.f)); A.brick.push_back(make_float4(qn, qn, qn, qn)); }
+    if (A.large_brick.empty()) A.large_brick.assign(2, make_float4(0, 0, 0, 0));
     A.cs.resize(2 * (ncell + 1));
     for (size_t c = 0; c <= ncell; ++c) { A.cs[c] = cs_x[c]; A.cs[ncell + 1 + c] = (int32_t)total + cs_z[c]; }
     p.zoff = (int32_t)(ncell + 1);

@@ -242,14 +242,14 @@ int rt_octree_upload(rt_octree* O) {
     if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_hot, &O->d_ent_hot)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
     O->dev.nodes4 = (const float4*)O->d_nodes; O->dev.ent_hot = (const float4*)O->d_ent_hot; O->dev.ent_id = (const int32_t*)O->d_ent_id;
     AccelHost& A = O->accel;
-    if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_id, &O->d_acc[1])) || (rc = upload(A.cs, &O->d_acc[2])) ||
-        (rc = upload(A.hot, &O->d_acc[3])) || (rc = upload(A.id, &O->d_acc[4])) || (rc = upload(A.memb_start, &O->d_acc[5])) ||
-        (rc = upload(A.memb_cell, &O->d_acc[6])) || (rc = upload(A.node1, &O->d_acc[7])) || (rc = upload(A.cellnode, &O->d_acc[8])) ||
+    if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_brick, &O->d_acc[1])) || (rc = upload(A.cs, &O->d_acc[2])) ||
+        (rc = upload(A.hot, &O->d_acc[3])) || (rc = upload(A.brick, &O->d_acc[4])) || (rc = upload(A.memb_start, &O->d_acc[5])) ||
+        (rc = upload(A.memb_cell, &O->d_acc[6])) || (rc = upload(A.cellnode, &O->d_acc[8])) ||
         (rc = upload(A.bits_index, &O->d_acc[9])) || (rc = upload(A.cellbits, &O->d_acc[10]))) return rc;
     DevAccel& p = A.p;
-    p.large_hot = (const float4*)O->d_acc[0]; p.large_id = (const int32_t*)O->d_acc[1];
-    p.cs = (const int32_t*)O->d_acc[2]; p.hot = (const float4*)O->d_acc[3]; p.id = (const int32_t*)O->d_acc[4];
-    p.memb_start = (const int32_t*)O->d_acc[5]; p.memb_cell = (const int32_t*)O->d_acc[6]; p.node1 = (const int32_t*)O->d_acc[7]; p.cellnode = (const int32_t*)O->d_acc[8];
+    p.large_hot = (const float4*)O->d_acc[0]; p.large_brick = (const float4*)O->d_acc[1];
+    p.cs = (const int32_t*)O->d_acc[2]; p.hot = (const float4*)O->d_acc[3]; p.brick = (const float4*)O->d_acc[4];
+    p.memb_start = (const int32_t*)O->d_acc[5]; p.memb_cell = (const int32_t*)O->d_acc[6]; p.cellnode = (const int32_t*)O->d_acc[8];
     p.bits_index = (const int32_t*)O->d_acc[9]; p.cellbits = (const uint32_t*)O->d_acc[10];
     O->dev.acc = p;
     O->uploaded = true;

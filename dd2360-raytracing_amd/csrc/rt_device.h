@@ -37,14 +37,16 @@ struct DevScene {
 // that the reference's traversal visits is then checked with the reference's own slab test.
 struct DevAccel {
     const float4* large_hot;   // [n_large] (cx,cy,cz,r^2): tree spheres too big (or too far out) for the grid, always tested
-    const int32_t* large_id;   // [n_large]
+    const float4* large_brick; // [2*n_large] as `brick`
     // Two copies of the grid so that the cells a ray crosses inside one column of its major axis are contiguous:
     // x-major (cell (ix,iz) at ix*G+iz) in cs[0 .. G*G], z-major (cell at iz*G+ix) in cs[zoff .. zoff+G*G];
     // cs values index hot[] / id[] directly (the z-major copy's entries follow the x-major copy's).
     const int32_t* cs;
     const float4* hot;         // (cx,cy,cz,r^2)
-    const int32_t* id;         // world-list index
-    const int32_t* node1;      // per entry: the single level-3 node (pre-order index) that stores the sphere, or -1 if several do
+    // per entry two float4: (lo.x, lo.y, lo.z, bits of the world-list index), (hi.x, hi.y, hi.z, bits of node1) —
+    // lo/hi = the sphere's brick in level-3 cell coordinates, margins included (rt_accel.h), lo = +inf when it has none;
+    // node1 = the single level-3 node (pre-order index) that stores the sphere, or -1 if several do
+    const float4* brick;
     int32_t zoff;
     const int32_t* memb_start; // [n+1] per world-list index: range in memb_cell
     const int32_t* memb_cell;  // pre-order node index (DevNode) of each level-3 node whose buckets hold the sphere

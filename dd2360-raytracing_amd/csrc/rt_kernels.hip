@@ -82,16 +82,21 @@ namespace rt {
 enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
        ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_LIVE_GE56, ST_LIVE_32, ST_LIVE_8, ST_LIVE_LT8, ST_SWITCHES,
        ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME,
-       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_SPARE6, ST_N };
+       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_SPARE6,
+       // wave passes: how often a wave (any lane) executed a block — multiplied by the block's static size = issue slots
+       WP_GROUND, WP_LARGE_K, WP_LARGE_EXACT, WP_OFFER_NODE, WP_OFFER_RAYBOX, WP_ELIG_FN, WP_ELIG_LIST, WP_SETUP, WP_A_COL, WP_A_BATCH, WP_A_HOLD,
+       WP_B_OFFER, WP_B_CLIP, WP_COOP_CHUNK, WP_SCAN, WP_SC_ANY, WP_SC_LAMB, WP_SC_METAL, WP_SC_DIEL, WP_REJ_ITER, WP_PRIMARY, WP_DISK_ITER, WP_SKY, WP_ENDPIX, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
 struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
 #define STAT(st, k, v) ((st).c[k] += (v))
+#define WPASS(k) do { const int l_ = (int)(threadIdx.x & 63); if (__builtin_amdgcn_readfirstlane(l_) == l_) atomicAdd(&g_stats[k], 1ull); } while (0)
 #define STAT_ARG , Stats& st
 #define STAT_PASS , st
 #else
 #define STAT(st, k, v) ((void)0)
+#define WPASS(k) ((void)0)
 #define STAT_ARG
 #define STAT_PASS
 #endif
@@ -261,7 +266,7 @@ RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 // component a node's slab test passing implies all its ancestors' tests pass (their intervals contain the child's),
 // so the node's own test — the reference's arithmetic — decides.
 RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int sphere STAT_ARG) {
-    STAT(st, ST_ELIG, 1);
+    STAT(st, ST_ELIG, 1); WPASS(WP_ELIG_FN);
     // Shortcut for spheres stored in several nodes (the big ones): the level-3 cell that contains the hit point.  If the
     // point keeps 0.012 from all six faces of that cell, the hit's t lies inside all three float slab intervals of the
     // cell (rounding errors are ~1e-5), so that node's slab test passes; it remains to see that the sphere is stored
@@ -285,7 +290,7 @@ RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, flo
     const int mb = T.acc.memb_start[sphere], me = T.acc.memb_start[sphere + 1];
     for (int k = mb; k < me; ++k) {
         const int node = T.acc.memb_cell[k];
-        STAT(st, ST_ELIG_NODES, 1);
+        STAT(st, ST_ELIG_NODES, 1); WPASS(WP_ELIG_LIST);
         const float4 n0 = s_nodes[node * 3 + 0];
         const float4 n1 = s_nodes[node * 3 + 1];
         if (ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y)) return true;
@@ -293,24 +298,35 @@ RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, flo
     return false;
 }
 
-// node1 >= 0: the sphere is stored in exactly that level-3 node (no membership lookup needed); -1: look the list up
-RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int id, int node1, float& best_t, int& best, bool& tie STAT_ARG) {
+// Does the hit at `cand` lie inside the sphere's brick (rt_accel.h: the box of level-3 cells that ALL store the sphere, in
+// cell coordinates, margins included)?  Then it lies in a stored cell whose three float slab intervals contain the hit's t
+// (the hit point keeps 0.012 from the brick's outer faces, rounding moves an interval end by ~1e-5; inner faces are shared
+// planes, so the cells' intervals tile the brick's without gaps): that node passes the reference's slab test, and with it
+// its ancestors — no division needed.  Approximate arithmetic is fine here: the margins hold >= 5e-4.
+RT_DEV bool in_brick(const RayF& r, float cand, const float4 blo, const float4 bhi) {
+    const float ux = __builtin_fmaf(__builtin_fmaf(cand, r.d.x, r.o.x), 1.0f / 2.75f, 4.0f);
+    const float uy = __builtin_fmaf(cand, r.d.y, r.o.y) * 4.0f;
+    const float uz = __builtin_fmaf(__builtin_fmaf(cand, r.d.z, r.o.z), 1.0f / 2.75f, 4.0f);
+    return ux > blo.x && ux < bhi.x && uy > blo.y && uy < bhi.y && uz > blo.z && uz < bhi.z;
+}
+
+// blo/bhi: the candidate's DevAccel::brick pair (brick bounds, world-list index, single storing node or -1)
+RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, const float4 blo, const float4 bhi, float& best_t, int& best, bool& tie STAT_ARG) {
     STAT(st, ST_OFFERS, 1);
+    const int id = __float_as_int(blo.w);
     if (cand < best_t) {
-        bool ok;
-        if (node1 >= 0) {
-            STAT(st, ST_ELIG, 1);
-            const int nd = node1 & 0x3fffffff;
-            const float4 n0 = s_nodes[nd * 3 + 0];
-            const float4 n1 = s_nodes[nd * 3 + 1];
-            // Sphere interior to its node in x and z (host flag) and hit point well inside the node in y: the hit's t lies
-            // inside all three float slab intervals (margins 0.02 / 0.012 against rounding errors of ~1e-5), so every
-            // comparison of intersect_ray_aabb comes out "overlap" — the six divisions are not needed to know it passes.
-            const float py = r.o.y + cand * r.d.y;
-            if ((node1 & 0x40000000) && py > n0.y + 0.012f && py < n1.x - 0.012f) ok = true;
-            else { STAT(st, ST_ELIG_NODES, 1); ok = ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y); }
-        } else {
-            ok = eligible(T, s_nodes, r, cand, id STAT_PASS);
+        bool ok = in_brick(r, cand, blo, bhi);
+        if (!ok) {
+            // hit point near an outer face of the brick, or no brick (a bucket was full): the reference's own slab test
+            const int node1 = __float_as_int(bhi.w);
+            if (node1 >= 0) {
+                STAT(st, ST_ELIG, 1); STAT(st, ST_ELIG_NODES, 1); WPASS(WP_OFFER_RAYBOX);
+                const float4 n0 = s_nodes[node1 * 3 + 0];
+                const float4 n1 = s_nodes[node1 * 3 + 1];
+                ok = ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+            } else {
+                ok = eligible(T, s_nodes, r, cand, id STAT_PASS);
+            }
         }
         if (ok) { best_t = cand; best = id; }
     } else if (cand == best_t && id != best && best > 0) {
@@ -411,7 +427,7 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
         const int stp = Q.fwd ? 1 : -1;
         const float ra = __builtin_amdgcn_rcpf(qa);
         while (Q.i != Q.iend) {
-            STAT(st, ST_A_ITERS_WAVE, 1);
+            STAT(st, ST_A_ITERS_WAVE, 1); WPASS(WP_COOP_CHUNK);
             const int left = Q.fwd ? (Q.iend - Q.i) : (Q.i - Q.iend);
             const int ncol = left < 8 ? left : 8;
             int eb = 0, cnt = 0;
@@ -456,17 +472,18 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                     int id = -1;
                     bool elig = false;
                     if (want) {
-                        id = A.id[e];
-                        const int nd = A.node1[e];
+                        const float4 blo = A.brick[2 * e], bhi = A.brick[2 * e + 1];
+                        id = __float_as_int(blo.w);
                         if (cand < bt) {
-                            if (nd >= 0) {
-                                const int nn = nd & 0x3fffffff;
-                                const float4 n0 = s_nodes[nn * 3 + 0]; const float4 n1 = s_nodes[nn * 3 + 1];
-                                const float py = q.o.y + cand * q.d.y;
-                                if ((nd & 0x40000000) && py > n0.y + 0.012f && py < n1.x - 0.012f) elig = true;      // see offer()
-                                else elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+                            elig = in_brick(q, cand, blo, bhi);
+                            if (!elig) {
+                                const int nd = __float_as_int(bhi.w);
+                                if (nd >= 0) {
+                                    const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1];
+                                    elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+                                }
+                                else elig = eligible(T, s_nodes, q, cand, id STAT_PASS);
                             }
-                            else elig = eligible(T, s_nodes, q, cand, id STAT_PASS);
                         }
                     }
                     // an equal t from a different tree sphere than the current best: the visit order would decide
@@ -514,7 +531,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
     int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
     int used = 0;                                            // phase-A iterations of this call (wave-uniform)
     float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
-    int p_id = 0, p_node = -1;
+    float4 p_lo = make_float4(0.f, 0.f, 0.f, 0.f), p_hi = p_lo;
     // A thin wave has nothing to hide an L2 round trip behind (~1000 cycles per dependent load), and the frame cannot end
     // before its longest pixel chain does — so the walk keeps several loads in flight: the cell range of the next
     // column is fetched while the current column's entries are tested, and entries are tested four at a time.
@@ -548,7 +565,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
             if (searching) {
                 STAT(st, ST_A_LANE_STEPS, 1);
                 if (e >= e_end && i != iend) {                 // enter the next column (its range was fetched a step ago)
-                    STAT(st, ST_COLS, 1);
+                    STAT(st, ST_COLS, 1); WPASS(WP_A_COL);
                     e = ne; e_end = ne_end;
                     i += step;
                     if (i != iend) prefetch_col();
@@ -560,7 +577,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                     // of this range may be held.
                     const float4* __restrict__ hp = hot + e;
                     const int rem = e_end - e;
-                    STAT(st, ST_TESTS, rem < RT_BATCH ? rem : RT_BATCH);
+                    STAT(st, ST_TESTS, rem < RT_BATCH ? rem : RT_BATCH); WPASS(WP_A_BATCH);
                     float4 s4[RT_BATCH];
 #pragma unroll
                     for (int k = 0; k < RT_BATCH; ++k) s4[k] = hp[k];
@@ -583,8 +600,8 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                     }
                     if (kf < RT_BATCH) {
                         p_b = bf; p_disc = df; p_e = e + kf;
-                        p_id = A.id[e + kf]; p_node = A.node1[e + kf];                  // in flight until phase B
-                        STAT(st, ST_DISCPOS, 1);
+                        p_lo = A.brick[2 * (e + kf)]; p_hi = A.brick[2 * (e + kf) + 1];       // in flight until phase B
+                        STAT(st, ST_DISCPOS, 1); WPASS(WP_A_HOLD);
                         e += kf + 1;
                     } else {
                         e += RT_BATCH;
@@ -612,8 +629,10 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
         }
         if (cand <= best_t) {
             const float before = best_t;
-            offer(T, s_nodes, r, cand, p_id, p_node, best_t, best, tie STAT_PASS);
+            WPASS(WP_B_OFFER);
+            offer(T, s_nodes, r, cand, p_lo, p_hi, best_t, best, tie STAT_PASS);
             if (best_t < before) {
+                WPASS(WP_B_CLIP);
                 clip_to_hit();
                 if (fwd ? (i >= iend) : (i <= iend)) { i = iend; }
             }
@@ -641,6 +660,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     STAT(st, ST_RAYS, fresh ? 1 : 0);
     if (fresh) { closest = FLT_MAX; best = -1; }
     if (S.ground_valid && fresh) {
+        WPASS(WP_GROUND);
         const float4 g = S.list_hot[0];
         int gb = -1;
         sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
@@ -663,6 +683,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             for (int k = 0; k < T.acc.n_large; ++k) {
                 // same cheap pre-filter as in the walk: exact roots only for a sphere that can still win
                 const float4 sp = T.acc.large_hot[k];
+                WPASS(WP_LARGE_K);
                 const float ocx = r.o.x - sp.x, ocy = r.o.y - sp.y, ocz = r.o.z - sp.z;
                 const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
                 const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w;
@@ -673,15 +694,17 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                     const bool behind = (sqa - b) * ra + m < 0.001f;
                     const bool beyond = (-b - sqa) * ra - m > closest;
                     if (!behind && !beyond) {
+                        WPASS(WP_LARGE_EXACT);
                         const float sq = sqrtf(disc);
                         float cand = __builtin_inff();
                         const float t1 = (-b - sq) / a;
                         if (t1 > 0.001f) cand = t1;
                         else { const float t2 = (-b + sq) / a; if (t2 > 0.001f) cand = t2; }
-                        offer(T, s_nodes, r, cand, T.acc.large_id[k], -1, closest, best, ts.tie STAT_PASS);
+                        offer(T, s_nodes, r, cand, T.acc.large_brick[2 * k], T.acc.large_brick[2 * k + 1], closest, best, ts.tie STAT_PASS);
                     }
                 }
             }
+            WPASS(WP_SETUP);
             ts.W = walk_setup(T.acc, r, closest, best);
             ts.e = 0; ts.e_end = 0;
         }
@@ -702,7 +725,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
 #ifdef RT_STATS
     const unsigned long long tS0 = TICK(); st.cyc[1] += tS0 - tG;     // fast path (large spheres + setup + walk), wave time
 #endif
-    if (__ballot(slow) != 0ull) tree_scan(T, s_nodes, r, a, slow, closest, best);
+    if (__ballot(slow) != 0ull) { WPASS(WP_SCAN); tree_scan(T, s_nodes, r, a, slow, closest, best); }
 #ifdef RT_STATS
     st.cyc[3] += TICK() - tS0;
 #endif
@@ -712,6 +735,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
 RT_DEV V3 random_in_unit_sphere(Rng& s) {               // material.h:35-41
     V3 p;
     do {
+        WPASS(WP_REJ_ITER);
         const float x = rng_uniform(s); const float y = rng_uniform(s); const float z = rng_uniform(s);
         p.x = 2.0f * x - 1.0f; p.y = 2.0f * y - 1.0f; p.z = 2.0f * z - 1.0f;
     } while (p.x * p.x + p.y * p.y + p.z * p.z >= 1.0f);
@@ -723,7 +747,9 @@ RT_DEV RayF primary_ray(const rt_camera& c, int i, int j, int max_x, int max_y, 
     const float u = ((float)i + rng_uniform(s)) / (float)max_x;
     const float v = ((float)j + rng_uniform(s)) / (float)max_y;
     float px, py;
+    WPASS(WP_PRIMARY);
     do {
+        WPASS(WP_DISK_ITER);
         const float x = rng_uniform(s); const float y = rng_uniform(s);
         px = 2.0f * x - 1.0f; py = 2.0f * y - 1.0f;
     } while (px * px + py * py + 0.0f >= 1.0f);
@@ -748,8 +774,10 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
     // lambertian and metal both draw exactly one random_in_unit_sphere and nothing else: one shared rejection loop
     // (the slowest lane of a wave sets its length) instead of one per material branch; the draw order is unchanged
     V3 q = {0.0f, 0.0f, 0.0f};
+    WPASS(WP_SC_ANY);
     if (kind != RT_MAT_DIELECTRIC) q = random_in_unit_sphere(s);
     if (kind == RT_MAT_LAMBERTIAN) {                                                          // material.h:55-60
+        WPASS(WP_SC_LAMB);
         const float tx = (p.x + n.x) + q.x, ty = (p.y + n.y) + q.y, tz = (p.z + n.z) + q.z;
         r.d.x = tx - p.x; r.d.y = ty - p.y; r.d.z = tz - p.z;
         r.o = p;
@@ -757,6 +785,7 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
         return true;
     }
     if (kind == RT_MAT_METAL) {                                                               // material.h:68-73
+        WPASS(WP_SC_METAL);
         const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
         V3 ud; ud.x = r.d.x / len; ud.y = r.d.y / len; ud.z = r.d.z / len;
         const float k = 2.0f * dot3(ud, n);
@@ -767,6 +796,7 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
         return dot3(r.d, n) > 0.0f;
     }
     // dielectric — material.h:81-113 (attenuation (1,1,1): the multiply is exact and omitted)
+    WPASS(WP_SC_DIEL);
     const float ri = m.w;
     const float dn = dot3(r.d, n);
     const float k = 2.0f * dn;
@@ -804,6 +834,7 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
 
 // background gradient of color() — main.cu:67-72
 RT_DEV V3 sky(const RayF& r, const V3& att) {
+    WPASS(WP_SKY);
     const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
     const float uy = r.d.y / len;
     const float t = 0.5f * (uy + 1.0f);
@@ -1043,6 +1074,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 #ifdef RT_STATS
                     pix_steps = st.c[ST_A_LANE_STEPS] - steps_mark; steps_mark = st.c[ST_A_LANE_STEPS];
 #endif
+                    WPASS(WP_ENDPIX);
                     end_pixel();
 #ifdef RT_STATS
                     pix_iters = 0;

@@ -65,3 +65,10 @@ print("wave-cycles (summed over waves): total %.0fM, closest-hit %.1f%% (fast pa
     cyc[0] / 1e6, 100 * cyc[1] / cyc[0], 100 * cyc[2] / cyc[0], 100 * cyc[3] / cyc[0], 100 * cyc[4] / cyc[0], 100 * cyc[5] / cyc[0]))
 print("  inside the fast path: large spheres + set-up %.1f%% of total wave-cycles" % (100 * raw[33] / cyc[0]))
 print("  phase B (roots + offer) of the per-lane walk: %.1f%% of total wave-cycles" % (100 * raw[34] / cyc[0]))
+
+wp = ["ground", "large_k", "large_exact", "offer_node", "offer_raybox", "elig_fn", "elig_list", "setup", "A_col", "A_batch", "A_hold",
+      "B_offer", "B_clip", "coop_chunk", "scan", "scatter", "sc_lambert", "sc_metal", "sc_dielectric", "rej_iter", "primary", "disk_iter", "sky", "end_pixel"]
+li = max(1, v["loop_iters_wave"])
+print("wave passes per main-loop iteration (a block executed by >= 1 lane of the wave):")
+for k, name in enumerate(wp):
+    print("  %-14s %8.3f" % (name, raw[35 + k] / li))
