@@ -167,6 +167,16 @@ RT_DEV bool ray_box(const RayF& r, float lox, float loy, float loz, float hix, f
 }
 
 // ---------------------------------------------------------------------------------------------------- closest hit
+// Every kernel that traces rays takes a RenderArgs as its FIRST argument.  The launch arguments again, read from the kernarg segment at the point of use.  Fields taken from the by-value argument
+// live in SGPRs for the whole kernel; the render loop is short of SGPRs (spills cost VALU slots: v_readlane/v_writelane),
+// so everything that is only needed between pixels or once per bounce (camera, queue, order, framebuffer, materials) is
+// re-read through this pointer (scalar loads, no VALU) — the empty asm keeps the compiler from hoisting those loads.
+RT_DEV const RenderArgs* cold_args() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const RenderArgs*)p;
+}
+
 RT_DEV float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 RT_DEV int bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
@@ -234,7 +244,8 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
 // The reference scan: the tree in the reference's depth-first order (pre-order array + skip links), every bucket entry
 // of every visited level-3 node.  While-while form: each lane first advances to its next non-empty level-3 node that
 // passes the slab test, then scans that node's entries.  `closest`/`best` come in holding the ground-sphere result.
-RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
+RT_DEV void tree_scan(const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
+    const DevTree& T = cold_args()->tree;
     int e_best = -1;
     int node = live ? 0 : T.n_nodes;
     const int n_nodes = T.n_nodes;
@@ -265,7 +276,8 @@ RT_DEV void tree_scan(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 // Is the sphere stored in a level-3 node that the reference's traversal visits for this ray?  With no zero direction
 // component a node's slab test passing implies all its ancestors' tests pass (their intervals contain the child's),
 // so the node's own test — the reference's arithmetic — decides.
-RT_DEV bool eligible(const DevTree& T, const float4* s_nodes, const RayF& r, float cand, int sphere STAT_ARG) {
+RT_DEV bool eligible(const float4* s_nodes, const RayF& r, float cand, int sphere STAT_ARG) {
+    const DevTree& T = cold_args()->tree;
     STAT(st, ST_ELIG, 1); WPASS(WP_ELIG_FN);
     // Shortcut for spheres stored in several nodes (the big ones): the level-3 cell that contains the hit point.  If the
     // point keeps 0.012 from all six faces of that cell, the hit's t lies inside all three float slab intervals of the
@@ -325,7 +337,7 @@ RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float 
                 const float4 n1 = s_nodes[node1 * 3 + 1];
                 ok = ray_box(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
             } else {
-                ok = eligible(T, s_nodes, r, cand, id STAT_PASS);
+                ok = eligible(s_nodes, r, cand, id STAT_PASS);
             }
         }
         if (ok) { best_t = cand; best = id; }
@@ -482,7 +494,7 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                                     const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1];
                                     elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
                                 }
-                                else elig = eligible(T, s_nodes, q, cand, id STAT_PASS);
+                                else elig = eligible(s_nodes, q, cand, id STAT_PASS);
                             }
                         }
                     }
@@ -725,7 +737,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
 #ifdef RT_STATS
     const unsigned long long tS0 = TICK(); st.cyc[1] += tS0 - tG;     // fast path (large spheres + setup + walk), wave time
 #endif
-    if (__ballot(slow) != 0ull) { WPASS(WP_SCAN); tree_scan(T, s_nodes, r, a, slow, closest, best); }
+    if (__ballot(slow) != 0ull) { WPASS(WP_SCAN); tree_scan(s_nodes, r, a, slow, closest, best); }
 #ifdef RT_STATS
     st.cyc[3] += TICK() - tS0;
 #endif
@@ -920,6 +932,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     // claim `slot` (skipping slots that fall outside the frame in edge tiles) and set the lane up for that pixel
     auto begin_pixel = [&]() {
         live = false;
+        const RenderArgs& A = *cold_args();
 #ifdef RT_ONLY_LANE
         if (lane != RT_ONLY_LANE) return;                  // probe build: one pixel chain alone in its wave
 #endif
@@ -955,6 +968,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     // take the next pre-classified long chain, if any is left (lanes 0..RT_LONG_PER_WAVE-1 only)
     auto begin_long_pixel = [&]() -> bool {
         if (!use_long || long_done) return false;
+        const RenderArgs& A = *cold_args();
         const unsigned int h = atomicAdd(A.queue + 3, 1u);
         if (h >= n_long) { long_done = true; return false; }
         const long long pid = (long long)A.long_list[h];
@@ -973,6 +987,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     };
     // rand_state[pixel_index] = local_rand_state; fb[pixel_index] = ...  (main.cu:110-115 / :133-141)
     auto end_pixel = [&]() {
+        const RenderArgs& A = *cold_args();
         rt_rand_state* st_out = A.rand_state + idx;
         st_out->d = s.d; st_out->v[0] = s.v0; st_out->v[1] = s.v1; st_out->v[2] = s.v2; st_out->v[3] = s.v3; st_out->v[4] = s.v4;
         float* fb = (float*)A.fb + idx * 3;
@@ -998,7 +1013,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     // start: pre-classified long chains first, RT_LONG_PER_WAVE per wave, in waves that are thin from the beginning
     if (lane < RT_LONG_PER_WAVE) begin_long_pixel();
     if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
-    else { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+    else { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
 
     const unsigned int thin_cap = (unsigned int)(n_waves / 4);
     float closest = FLT_MAX; int best = -1;
@@ -1011,10 +1026,10 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (!thin && m_long != 0ull) {
             // try to become a thin wave; if the cap is reached these pixels simply stay ordinary
             unsigned int prev = 0;
-            if (lane == 0) prev = atomicAdd(A.queue + 1, 1u);
+            if (lane == 0) prev = atomicAdd(cold_args()->queue + 1, 1u);
             prev = __builtin_amdgcn_readfirstlane(prev);
             if (prev < thin_cap) { thin = true; thin_counted = true; __builtin_amdgcn_s_setprio(3); }       // the chain is on the critical path: win issue arbitration
-            else { if (lane == 0) atomicSub(A.queue + 1, 1u); is_long = false; }
+            else { if (lane == 0) atomicSub(cold_args()->queue + 1, 1u); is_long = false; }
         } else if (thin && m_long == 0ull) {
             thin = false; __builtin_amdgcn_s_setprio(0);
             if (thin_counted && lane == 0) atomicSub(A.queue + 1, 1u);
@@ -1022,7 +1037,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         }
         if (!thin) {
             // idle lanes (their pixel ended while the wave was thin) go back to the queue
-            if (!live && !retired) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+            if (!live && !retired) { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
         }
         // thin implies a live long pixel; otherwise every lane that is not live has just found the queue empty
         if (__ballot(live) == 0ull) break;
@@ -1051,7 +1066,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             ++iters;
             bool done;                                     // this sample's path has ended
             if (best >= 0) {
-                const bool cont = scatter(A.scene, best, closest, r, att, s);
+                const bool cont = scatter(cold_args()->scene, best, closest, r, att, s);
                 ++depth;
                 done = !cont || depth >= 50;               // absorbed, or 50 bounces used up: contributes (0,0,0)
             } else {
@@ -1062,7 +1077,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             if (done) {
                 ++sample; depth = 0; att = {1.0f, 1.0f, 1.0f};
                 if (sample < ns) {
-                    r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, s);
+                    { const RenderArgs& C = *cold_args(); r = primary_ray(C.scene.cam, i, j, C.max_x, C.max_y, s); }
                     // classify after every 4th sample while enough of the chain is left for it to matter
                     if ((sample & 7) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_LONG_RATE * sample)) {
 #ifdef RT_STATS
@@ -1082,7 +1097,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                     STAT(st, ST_SWITCHES, 1);
                     live = false; is_long = false;
                     if (lane < RT_LONG_PER_WAVE && begin_long_pixel()) { /* next long chain */ }
-                    else if (!thin) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+                    else if (!thin) { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
                 }
             }
         }
@@ -1219,7 +1234,8 @@ __global__ __launch_bounds__(64) void k_tile_order(const int* __restrict__ cost,
 
 // hitTree / hitable_list::hit for a batch of rays (one lane per ray)
 template <bool TREE>
-__global__ __launch_bounds__(256) void k_trace(DevScene S, DevTree T, const float* rays, long long n, rt_hit_record* out) {
+__global__ __launch_bounds__(256) void k_trace(RenderArgs A, const float* rays, long long n, rt_hit_record* out) {
+    const DevScene& S = A.scene; const DevTree& T = A.tree;
     extern __shared__ float4 s_nodes[];
     if (TREE) {
         const int n4 = T.n_nodes * 3;
@@ -1320,8 +1336,10 @@ hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const fl
     if (n <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) : 0;
-    if (tree) hipLaunchKernelGGL((k_trace<true>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
-    else hipLaunchKernelGGL((k_trace<false>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
+    RenderArgs A{};
+    A.scene = S; A.tree = T;
+    if (tree) hipLaunchKernelGGL((k_trace<true>), dim3(blocks), dim3(256), lds, st, A, rays, n, out);
+    else hipLaunchKernelGGL((k_trace<false>), dim3(blocks), dim3(256), lds, st, A, rays, n, out);
     return hipGetLastError();
 }
 
