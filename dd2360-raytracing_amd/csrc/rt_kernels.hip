@@ -529,9 +529,13 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
     const DevAccel& A = T.acc;
     const int32_t* __restrict__ cs = A.cs;
     const float4* __restrict__ hot = A.hot;
-    const int G = A.G;
+    // The loop below is short of SGPRs (the compiler spills them to VGPR lanes and reloads whole 8-register tuples inside
+    // the loop, each reload a VALU slot): the grid size is kept in a VGPR instead, there are plenty of those.
+    int G = A.G;
+    asm volatile("" : "+v"(G));
     const float fG = (float)G;
-    const float s_c = 2e-3f * A.inv_h;
+    float s_c = 2e-3f * A.inv_h;
+    asm volatile("" : "+v"(s_c));
     const float om_c = W.om_c, on_c = W.on_c, slope = W.slope;
     const int coff = W.coff;
     const bool fwd = W.fwd;
