@@ -543,7 +543,9 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
     int i = W.i, iend = W.iend;
     bool walking = W.walking;
     auto clip_to_hit = [&]() { W.i = i; W.iend = iend; walk_clip(W, A, best_t); i = W.i; iend = W.iend; };
-    const float ra = __builtin_amdgcn_rcpf(a);
+    // pre-filter thresholds (see phase A): a(1+kap) t_best + 1e-6 a, refreshed when the best hit changes, and a(1-kap) t_min - 1e-6 a
+    float f_abt = __builtin_fmaf(a * best_t, 1.0001f, 1e-6f * a);
+    const float f_atm = a * (0.001f * 0.9999f - 1e-6f);
     int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
     int used = 0;                                            // phase-A iterations of this call (wave-uniform)
     float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
@@ -597,10 +599,14 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                     float4 s4[RT_BATCH];
 #pragma unroll
                     for (int k = 0; k < RT_BATCH; ++k) s4[k] = hp[k];
-                    // Cheap pre-filter, branch-free for the whole batch: approximate roots (v_sqrt / v_rcp, a few ulp) with
-                    // a margin 400x their error.  A sphere whose far root is surely <= t_min, or whose near root is surely
-                    // beyond the best hit, is rejected by sphere::hit whatever the exact roots are; the first sphere of
-                    // the batch that survives is held for phase B, the entries after it are examined again later.
+                    // Cheap pre-filter for the whole batch.  A sphere whose far root is surely <= t_min, or whose near root
+                    // is surely >= the best hit, is rejected by sphere::hit whatever its float roots are.  With S = sqrt(disc)
+                    // the float roots differ from (-b -+ S)/a by at most 3.1 u (|b| + S)/a; the tests below leave a margin of
+                    // kap (|b| + S)/a + 1e-6, kap = 1e-4 (~500x), and need no square root:
+                    //   near root beyond:  -b - kap|b| - a(1+kap) t_best - 1e-6 a  >  (1+kap) S   <=  L > 0 and L^2 > (1+3kap) disc
+                    //   far root behind:    b - kap|b| + a(1-kap) t_min  - 1e-6 a  >  (1+kap) S   <=  M > 0 and M^2 > (1+3kap) disc
+                    // (DESIGN.md App. A.5).  The first sphere of the batch that survives is held for phase B, the entries
+                    // after it are examined again later.
                     int kf = RT_BATCH; float bf = 0.0f, df = 0.0f;
 #pragma unroll
                     for (int k = RT_BATCH - 1; k >= 0; --k) {
@@ -608,10 +614,11 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                         const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
                         const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[k].w;
                         const float disc = b * b - a * c;
-                        const float sqa = __builtin_amdgcn_sqrtf(disc);
-                        const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
-                        const bool behind = (sqa - b) * ra + m < 0.001f;
-                        const bool beyond = (-b - sqa) * ra - m > best_t;
+                        const float kb = 1e-4f * fabsf(b);
+                        const float L = (-b - kb) - f_abt, M = (b - kb) + f_atm;
+                        const float dk = disc * 1.0003f;
+                        const bool beyond = L > 0.0f && L * L > dk;
+                        const bool behind = M > 0.0f && M * M > dk;
                         if (disc > 0.0f && k < rem && !behind && !beyond) { kf = k; bf = b; df = disc; }
                     }
                     if (kf < RT_BATCH) {
@@ -649,6 +656,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
             offer(T, s_nodes, r, cand, p_lo, p_hi, best_t, best, tie STAT_PASS);
             if (best_t < before) {
                 WPASS(WP_B_CLIP);
+                f_abt = __builtin_fmaf(a * best_t, 1.0001f, 1e-6f * a);
                 clip_to_hit();
                 if (fwd ? (i >= iend) : (i <= iend)) { i = iend; }
             }

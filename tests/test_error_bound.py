@@ -75,3 +75,44 @@ def test_float_hit_point_stays_within_the_inflated_ball():
         t = ((-b[pos] + F(sign) * sq).astype(F) / a[pos]).astype(F)
         p = o[pos].astype(np.float64) + t.astype(np.float64)[:, None] * d[pos].astype(np.float64)
         assert (np.linalg.norm(p - c[pos].astype(np.float64), axis=1) <= R * (1 + 1e-4)).all()
+
+
+def test_walk_prefilter_never_rejects_an_acceptable_sphere():
+    """The square-root-free pre-filter of the grid walk (rt_kernels.hip, walk_lanes phase A) may only reject a
+    sphere whose float roots sphere::hit (sphere.h:24-43) would reject too.  Emulated in float32 numpy on cases built to sit ON the
+    decision boundaries: best hit within +-1e-3 (relative) of the near root, far root within +-1e-3 of t_min."""
+    rng = np.random.default_rng(5)
+    n = 1_500_000
+    kap = F(1e-4)
+    a = (10.0 ** rng.uniform(-6, 6, n)).astype(F)
+    S = (10.0 ** rng.uniform(-4, 3, n))                                           # sqrt(disc) wanted, in units of a
+    mode = rng.integers(0, 3, n)
+    eps = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-8, -3, n)
+    a64 = a.astype(np.float64)
+    # mode 0: near root ~ best_t (b < 0);  mode 1: far root ~ t_min;  mode 2: anything
+    t_near = 10.0 ** rng.uniform(-2, 2, n)
+    b = np.where(mode == 0, -(t_near * a64 + S * a64), np.where(mode == 1, S * a64 - 0.001 * a64 * (1.0 + eps), rng.normal(size=n) * S * a64 * 2)).astype(F)
+    disc = ((S * a64) ** 2).astype(F)
+    best_t = np.where(mode == 0, t_near * (1.0 + eps), 10.0 ** rng.uniform(-3, 3, n)).astype(F)
+    best_t[rng.random(n) < 0.05] = np.finfo(F).max                                # no hit yet
+    with np.errstate(over="ignore", invalid="ignore"):
+        # the reference's float roots and what it would offer
+        sq = np.sqrt(disc).astype(F)
+        t1 = ((-b - sq).astype(F) / a).astype(F)
+        t2 = ((-b + sq).astype(F) / a).astype(F)
+        cand = np.where(t1 > F(0.001), t1, np.where(t2 > F(0.001), t2, np.inf))
+        acceptable = cand <= best_t                                               # "<" accepts, "==" must still be seen (tie detection)
+        # the filter, as in the kernel (the fmaf is emulated in float64 and perturbed by an ulp either way below)
+        abt0 = ((a * best_t).astype(F).astype(np.float64) * float(F(1.0001)) + (F(1e-6) * a).astype(F).astype(np.float64)).astype(F)
+        atm = (a * F(F(0.001) * F(0.9999) - F(1e-6))).astype(F)
+        kb = (kap * np.abs(b)).astype(F)
+        M = ((b - kb).astype(F) + atm).astype(F)
+        dk = (disc * F(1.0003)).astype(F)
+        behind = (M > 0) & ((M * M).astype(F) > dk)
+        for abt in (abt0, np.nextafter(abt0, F(0)), np.nextafter(abt0, F(np.inf))):
+            L = ((-b - kb).astype(F) - abt).astype(F)
+            beyond = (L > 0) & ((L * L).astype(F) > dk)
+            reject = (disc > 0) & (beyond | behind)
+            assert not (reject & acceptable).any()
+    # the filter does something: most unacceptable boundary cases further than its margin are rejected
+    assert (reject & ~acceptable).sum() > 0.2 * (~acceptable).sum()
