@@ -68,6 +68,9 @@ namespace rt {
 #ifndef RT_PILOT_LONG
 #define RT_PILOT_LONG 60
 #endif
+#ifndef RT_PILOT_CAP
+#define RT_PILOT_CAP 50     // bounces after which a pilot sample is cut (the reference's depth limit: none)
+#endif
 // long chains started per thin wave
 #ifndef RT_LONG_PER_WAVE
 #define RT_LONG_PER_WAVE 2
@@ -1156,24 +1159,27 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    // quarter resolution: one pilot pixel per 2x2 block (long chains cluster); a wave covers four tiles, 16 lanes each
-    const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    // quarter resolution: one pilot pixel per 2x2 block (long chains cluster), its RT_PILOT_SAMPLES samples in adjacent
+    // lanes (the pass is as long as its longest serial chain); a wave covers 4 / RT_PILOT_SAMPLES tiles
+    constexpr int kPerTile = 16 * RT_PILOT_SAMPLES, kTilesPerWave = 64 / kPerTile;
+    static_assert(RT_PILOT_SAMPLES == 1 || RT_PILOT_SAMPLES == 2 || RT_PILOT_SAMPLES == 4, "pilot samples per pixel");
+    const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kTilesPerWave + lane / kPerTile;
     const bool tile_ok = local_tile < A.n_local_tiles;
     const long long tile = A.part + (tile_ok ? local_tile : 0) * A.nparts;
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
-    const int sub = lane & 15;
+    const int sub = (lane % kPerTile) / RT_PILOT_SAMPLES, smp = lane % RT_PILOT_SAMPLES;
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
     const int i = tx * 8 + lx, j = ty * 8 + ly;
     const bool inside = tile_ok && (i < A.max_x) && (j < A.max_y);
     // PILOT path: one sample per pixel on a private RNG stream (seeded away from the pixel's own 1984 + pixel_index
     // stream, which is not touched), same camera / closest-hit / scatter code as the render kernel; only the number
     // of bounces is kept.
-    Rng ps; rng_seed(ps, 0x5deece66dull + (unsigned long long)((long long)j * A.max_x + i));
+    Rng ps; rng_seed(ps, 0x5deece66dull + (unsigned long long)((long long)j * A.max_x + i) + (unsigned long long)smp * 0x9e3779b97f4a7c15ull);
     RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
     V3 att = {1.0f, 1.0f, 1.0f};
     bool live = inside;
     if (live) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, ps);
-    int bounces = 0, depth = 0, sample = 0;
+    int bounces = 0;
 #ifdef RT_STATS
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
@@ -1187,18 +1193,16 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
         if (live && !(TREE && ts.pending)) {
-            ++bounces; ++depth;
+            ++bounces;
             bool done = true;
-            if (best >= 0) { const bool cont = scatter(A.scene, best, closest, r, att, ps); done = !cont || depth >= 50; }
-            if (done) {
-                ++sample; depth = 0;
-                if (sample < RT_PILOT_SAMPLES) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, ps);
-                else live = false;
-            }
+            if (best >= 0) { const bool cont = scatter(A.scene, best, closest, r, att, ps); done = !cont || bounces >= RT_PILOT_CAP; }
+            if (done) live = false;
         }
     }
-    const bool is_long = inside && bounces >= RT_PILOT_LONG;
-    if (long_flag && tile_ok) {
+    int pix = inside ? bounces : 0;
+    for (int off = RT_PILOT_SAMPLES / 2; off > 0; off >>= 1) pix += __shfl_xor(pix, off);       // sum over the pixel's samples
+    const bool is_long = inside && pix >= RT_PILOT_LONG;
+    if (long_flag && tile_ok && smp == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                          // the 2x2 block this pilot pixel stands for
             const int px = lx + (q & 1), py = ly + (q >> 1);
@@ -1209,8 +1213,8 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
         }
     }
     int w = inside ? bounces : 0;
-    for (int off = 8; off > 0; off >>= 1) w += __shfl_xor(w, off);         // sum over the tile's 16 pilot pixels
-    if (sub == 0 && tile_ok) cost[local_tile] = w * 4;
+    for (int off = kPerTile / 2; off > 0; off >>= 1) w += __shfl_xor(w, off);         // sum over the tile's 16 pilot pixels x samples
+    if (lane % kPerTile == 0 && tile_ok) cost[local_tile] = w * 4;
 }
 
 RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (c > 7 ? 7 : c); }
@@ -1318,7 +1322,8 @@ template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
 
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((A.n_local_tiles + 15) / 16);       // a wave covers four tiles
+    const long long per_block = 4 * (64 / (16 * RT_PILOT_SAMPLES));       // a wave covers 4 / RT_PILOT_SAMPLES tiles
+    const unsigned blocks = (unsigned)((A.n_local_tiles + per_block - 1) / per_block);
     const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
     if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), lds, st, A, cost, flags, long_list);
     else hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), lds, st, A, cost, flags, long_list);
