@@ -44,6 +44,9 @@ namespace rt {
 #define RT_LONG_RATE 20
 #endif
 // waves with at most this many rays on the fast path walk the grid cooperatively (all lanes on one ray at a time)
+#ifndef RT_THIN_CAP_DEN
+#define RT_THIN_CAP_DEN 4   // at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
+#endif
 #ifndef RT_COOP_MAX
 #define RT_COOP_MAX 4
 #endif
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
     else { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
 
-    const unsigned int thin_cap = (unsigned int)(n_waves / 4);
+    const unsigned int thin_cap = (unsigned int)(n_waves / RT_THIN_CAP_DEN);
     float closest = FLT_MAX; int best = -1;
     TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
     ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
