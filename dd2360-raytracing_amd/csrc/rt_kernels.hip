@@ -37,7 +37,7 @@ namespace rt {
 #endif
 // phase B starts when holders * RT_VOTE_NUM >= searchers (or nobody searches)
 #ifndef RT_VOTE_NUM
-#define RT_VOTE_NUM 2
+#define RT_VOTE_NUM 3
 #endif
 // a pixel averaging at least this many bounces per sample is a long chain (the scene average is ~2.7)
 #ifndef RT_LONG_RATE
@@ -559,17 +559,17 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
     // A thin wave has nothing to hide an L2 round trip behind (~1000 cycles per dependent load), and the frame cannot end
     // before its longest pixel chain does — so the walk keeps several loads in flight: the cell range of the next
     // column is fetched while the current column's entries are tested, and entries are tested four at a time.
+    const float fGm = fG - 0.5f;
     auto prefetch_col = [&]() {
         // minor-axis extent of the line inside column i: lower edge at i, upper edge at i+1
         const float u0 = on_c + ((float)i - om_c) * slope, u1 = u0 + slope;
         const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-        int k0 = (int)floorf(fminf(fmaxf(lo, -1.0f), fG)), k1 = (int)floorf(fminf(fmaxf(hi, -1.0f), fG));
         ne = 0; ne_end = 0;
-        if (!(k1 < 0 || k0 > G - 1)) {
-            k0 = max(k0, 0); k1 = min(k1, G - 1);
-            const int cbase = coff + i * G;
-            ne = cs[cbase + k0];
-            ne_end = cs[cbase + k1 + 1];
+        if (hi >= 0.0f && lo < fG) {                          // cells max(floor(lo), 0) .. min(floor(hi), G-1)
+            const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGm);
+            const unsigned cbase = (unsigned)(coff + i * G);
+            ne = cs[cbase + (unsigned)k0];
+            ne_end = cs[cbase + (unsigned)k1 + 1u];
         }
     };
     if (walking && i != iend) prefetch_col();
