@@ -97,7 +97,11 @@ __device__ unsigned long long g_stats[ST_N];
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
 struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
 #define STAT(st, k, v) ((st).c[k] += (v))
+#ifdef RT_STATS_WPASS      // (the atomics distort every timing of the same run: a build of its own, librt_amd_wpass.so)
 #define WPASS(k) do { const int l_ = (int)(threadIdx.x & 63); if (__builtin_amdgcn_readfirstlane(l_) == l_) atomicAdd(&g_stats[k], 1ull); } while (0)
+#else
+#define WPASS(k) ((void)0)
+#endif
 #define STAT_ARG , Stats& st
 #define STAT_PASS , st
 #else

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
 import torch
 import rt_amd as rt
-rt.LIB_PATH = os.path.join(ROOT, "dd2360-raytracing_amd", "librt_amd_stats.so")
+rt.LIB_PATH = os.path.join(ROOT, "dd2360-raytracing_amd", os.environ.get("RT_STATS_LIB", "librt_amd_stats.so"))   # RT_STATS_LIB=librt_amd_wpass.so: wave passes
 L = rt.lib()
 L.rt_debug_stats.restype = C.c_int
 L.rt_debug_stats.argtypes = [C.c_void_p, C.c_int]
