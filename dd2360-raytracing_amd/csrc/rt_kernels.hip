@@ -91,7 +91,9 @@ enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFE
        ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_SPARE6,
        // wave passes: how often a wave (any lane) executed a block — multiplied by the block's static size = issue slots
        WP_GROUND, WP_LARGE_K, WP_LARGE_EXACT, WP_OFFER_NODE, WP_OFFER_RAYBOX, WP_ELIG_FN, WP_ELIG_LIST, WP_SETUP, WP_A_COL, WP_A_BATCH, WP_A_HOLD,
-       WP_B_OFFER, WP_B_CLIP, WP_COOP_CHUNK, WP_SCAN, WP_SC_ANY, WP_SC_LAMB, WP_SC_METAL, WP_SC_DIEL, WP_REJ_ITER, WP_PRIMARY, WP_DISK_ITER, WP_SKY, WP_ENDPIX, ST_N };
+       WP_B_OFFER, WP_B_CLIP, WP_COOP_CHUNK, WP_SCAN, WP_SC_ANY, WP_SC_LAMB, WP_SC_METAL, WP_SC_DIEL, WP_REJ_ITER, WP_PRIMARY, WP_DISK_ITER, WP_SKY, WP_ENDPIX,
+       // cycles of the iterations of thin waves with <= 2 live lanes, by part (the critical path of the frame's tail)
+       TH_GROUND, TH_LARGE_SETUP, TH_WALK, TH_SCAN, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
@@ -468,9 +470,13 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                 }
                 float cand = __builtin_inff();
                 bool want = false;
+                // the candidate's brick is fetched together with its sphere: a cooperative walk serves a wave that has nothing
+                // to hide a dependent L2 round trip behind (bandwidth is no concern there)
+                float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
                 if (have) {
                     STAT(st, ST_TESTS, 1);
                     const float4 s = A.hot[e];
+                    blo = A.brick[2 * e]; bhi = A.brick[2 * e + 1];
                     const float ocx = q.o.x - s.x, ocy = q.o.y - s.y, ocz = q.o.z - s.z;
                     const float b = ocx * q.d.x + ocy * q.d.y + ocz * q.d.z;
                     const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
@@ -494,7 +500,6 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                     int id = -1;
                     bool elig = false;
                     if (want) {
-                        const float4 blo = A.brick[2 * e], bhi = A.brick[2 * e + 1];
                         id = __float_as_int(blo.w);
                         if (cand < bt) {
                             elig = in_brick(q, cand, blo, bhi);
@@ -525,6 +530,116 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
         }
         if (lane == L) { best_t = bt; best = bi; tie = tie || tieL; W.walking = false; }
     }
+}
+
+
+// The cooperative walk for TWO rays at once, one per half-wave (a thin wave usually holds two chains: RT_LONG_PER_WAVE, and
+// the walk is half of the time a bounce takes there).  Same steps as walk_coop with 32 lanes per ray: up to 8 columns per
+// chunk, entries spread over the half's lanes, candidates resolved in parallel, minimum over the half.  Reads across lanes
+// are ds_bpermute (the source lane differs between the halves); ballots are masked with the half's lanes.
+RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int L0, int L1, float& best_t, int& best, bool& tie STAT_ARG) {
+    const DevAccel& A = T.acc;
+    const int lane = threadIdx.x & 63, g = lane >> 5, sl = lane & 31, gb = lane & 32;
+    const int Ls = g ? L1 : L0;                               // this half's ray lives in lane Ls
+    const unsigned long long gmask = g ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    RayF q;
+    q.o.x = __shfl(r.o.x, Ls); q.o.y = __shfl(r.o.y, Ls); q.o.z = __shfl(r.o.z, Ls);
+    q.d.x = __shfl(r.d.x, Ls); q.d.y = __shfl(r.d.y, Ls); q.d.z = __shfl(r.d.z, Ls);
+    const float qa = __shfl(a, Ls);
+    Walk Q;
+    Q.i = __shfl(W.i, Ls); Q.iend = __shfl(W.iend, Ls); Q.coff = __shfl(W.coff, Ls);
+    Q.om_c = __shfl(W.om_c, Ls); Q.on_c = __shfl(W.on_c, Ls); Q.slope = __shfl(W.slope, Ls); Q.dm_c = __shfl(W.dm_c, Ls);
+    Q.fwd = __shfl((int)W.fwd, Ls) != 0; Q.walking = true;
+    float bt = __shfl(best_t, Ls); int bi = __shfl(best, Ls);
+    bool tieL = false;
+    const int stp = Q.fwd ? 1 : -1;
+    const float ra = __builtin_amdgcn_rcpf(qa);
+    bool go = Q.i != Q.iend;                                  // uniform within a half
+    while (__ballot(go) != 0ull) {
+        STAT(st, ST_A_ITERS_WAVE, 1); WPASS(WP_COOP_CHUNK);
+        const int left = go ? (Q.fwd ? (Q.iend - Q.i) : (Q.i - Q.iend)) : 0;
+        const int ncol = left < 8 ? left : 8;
+        int eb = 0, cnt = 0;
+        if (sl < ncol) { int e1; column_range(A, Q, Q.i + sl * stp, eb, e1); cnt = e1 - eb; }
+        int incl = cnt;                                      // inclusive prefix over sub-lanes 0..7 of the half
+        { int t = __shfl_up(incl, 1); if (sl >= 1) incl += t; t = __shfl_up(incl, 2); if (sl >= 2) incl += t; t = __shfl_up(incl, 4); if (sl >= 4) incl += t; }
+        const int total = __shfl(incl, gb + 7);
+        int inc_m[8], cnt_m[8], eb_m[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { inc_m[m] = __shfl(incl, gb + m); cnt_m[m] = __shfl(cnt, gb + m); eb_m[m] = __shfl(eb, gb + m); }
+        const int t_other = __shfl(total, lane ^ 32);
+        const int t_any = total > t_other ? total : t_other;  // wave-uniform
+        for (int base = 0; base < t_any; base += 32) {
+            const int jdx = base + sl;
+            const bool have = jdx < total;
+            int e = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) if (jdx >= inc_m[m] - cnt_m[m] && jdx < inc_m[m]) e = eb_m[m] + (jdx - (inc_m[m] - cnt_m[m]));
+            float cand = __builtin_inff();
+            bool want = false;
+            float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
+            if (have) {
+                STAT(st, ST_TESTS, 1);
+                const float4 s = A.hot[e];
+                blo = A.brick[2 * e]; bhi = A.brick[2 * e + 1];
+                const float ocx = q.o.x - s.x, ocy = q.o.y - s.y, ocz = q.o.z - s.z;
+                const float b = ocx * q.d.x + ocy * q.d.y + ocz * q.d.z;
+                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
+                const float disc = b * b - qa * c;
+                if (disc > 0.0f) {
+                    const float sqa = __builtin_amdgcn_sqrtf(disc);
+                    const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
+                    const bool behind = (sqa - b) * ra + m < 0.001f;
+                    const bool beyond = (-b - sqa) * ra - m > bt;
+                    if (!behind && !beyond) {
+                        const float sq = sqrtf(disc);
+                        const float t1 = (-b - sq) / qa;
+                        if (t1 > 0.001f) cand = t1;
+                        else { const float t2 = (-b + sq) / qa; if (t2 > 0.001f) cand = t2; }
+                        want = cand <= bt;
+                    }
+                }
+            }
+            if (__ballot(want) != 0ull) {
+                STAT(st, ST_B_ROUNDS_WAVE, 1);
+                int id = -1;
+                bool elig = false;
+                if (want) {
+                    id = __float_as_int(blo.w);
+                    if (cand < bt) {
+                        elig = in_brick(q, cand, blo, bhi);
+                        if (!elig) {
+                            const int nd = __float_as_int(bhi.w);
+                            if (nd >= 0) {
+                                const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1];
+                                elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+                            }
+                            else elig = eligible(s_nodes, q, cand, id STAT_PASS);
+                        }
+                    }
+                }
+                // an equal t from a different tree sphere than the current best: the visit order would decide
+                if ((__ballot(want && cand == bt && id != bi && bi > 0) & gmask) != 0ull) tieL = true;
+                float mn = elig ? cand : __builtin_inff();
+                for (int off = 16; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+                const unsigned long long mm = __ballot(elig && cand == mn) & gmask;         // (empty when mn is +inf)
+                const int wl = mm != 0ull ? __ffsll((long long)mm) - 1 : lane;
+                const int wid = __shfl(id, wl);
+                const bool two = (__ballot(elig && cand == mn && id != wid) & gmask) != 0ull;
+                if (mn < bt) { if (two) tieL = true; bt = mn; bi = wid; }
+            }
+        }
+        if (go) {
+            Q.i += ncol * stp;
+            if (bi >= 0) walk_clip(Q, A, bt);
+            go = Q.i != Q.iend;
+        }
+    }
+    const float bt0 = __shfl(bt, 0), bt1 = __shfl(bt, 32);
+    const int bi0 = __shfl(bi, 0), bi1 = __shfl(bi, 32);
+    const int ti0 = __shfl((int)tieL, 0), ti1 = __shfl((int)tieL, 32);
+    if (lane == L0) { best_t = bt0; best = bi0; tie = tie || (ti0 != 0); W.walking = false; }
+    if (lane == L1) { best_t = bt1; best = bi1; tie = tie || (ti1 != 0); W.walking = false; }
 }
 
 // Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
@@ -749,7 +864,17 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         const int nw = __popcll(__ballot(walker));
         // the cooperative walk starts at a column boundary: not while a lane has a partly tested column
         const bool coop = nw > 0 && nw <= RT_COOP_MAX && __ballot(walker && ts.e < ts.e_end) == 0ull;
-        if (coop) walk_coop(T, s_nodes, r, a, ts.W, walker, closest, best, ts.tie STAT_PASS);
+        if (coop) {
+            // two rays at a time (one per half-wave), a last odd one with all 64 lanes
+            const int lane_ = threadIdx.x & 63;
+            unsigned long long todo = __ballot(walker && ts.W.walking);
+            while (__popcll(todo) >= 2) {
+                const int L0 = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
+                const int L1 = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
+                walk_coop2(T, s_nodes, r, a, ts.W, L0, L1, closest, best, ts.tie STAT_PASS);
+            }
+            if (todo != 0ull) walk_coop(T, s_nodes, r, a, ts.W, lane_ == __ffsll((long long)todo) - 1, closest, best, ts.tie STAT_PASS);
+        }
         else if (walker) walk_lanes(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
         if (walker) {
             ts.pending = ts.W.walking;
@@ -1032,6 +1157,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
     const unsigned long long tK0 = TICK(), rK0 = __builtin_amdgcn_s_memrealtime();
     unsigned int dbg_thin_iters = 0, dbg_long = 0;
+    unsigned long long th[4] = {0, 0, 0, 0};
     unsigned long long dbg_thin_cyc = 0, dbg_thin_closest = 0, dbg_thin1_cyc = 0; unsigned int dbg_thin1_iters = 0; unsigned long long dbg_t_prev = TICK();
 #endif
     // start: pre-classified long chains first, RT_LONG_PER_WAVE per wave, in waves that are thin from the beginning
@@ -1079,11 +1205,14 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (!TREE) { closest = FLT_MAX; best = -1; }
 #ifdef RT_STATS
         const unsigned long long tC0 = TICK();
+        const unsigned long long c4_ = st.cyc[4], c5_ = st.cyc[5], c1_ = st.cyc[1], c3_ = st.cyc[3];
+        const bool thin12 = thin && __popcll(__ballot(live)) <= 2;
 #endif
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
 #ifdef RT_STATS
         const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0; if (thin) dbg_thin_closest += tC1 - tC0;
+        if (TREE && thin12) { th[0] += (st.cyc[4] - c4_) - tC0; th[1] += st.cyc[5] - c5_; th[2] += (st.cyc[1] - c1_) - (st.cyc[5] - c5_); th[3] += st.cyc[3] - c3_; }
         if (live) { ++pix_iters; }
 #endif
         if (live && !(TREE && ts.pending)) {
@@ -1140,6 +1269,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (wv < 8192) {
             g_wave_dbg[wv * 4 + 0] = __builtin_amdgcn_s_memrealtime();
             g_wave_dbg[wv * 4 + 1] = st.c[ST_LOOP_ITERS_WAVE]; g_wave_dbg[wv * 4 + 2] = dbg_thin_iters; g_wave_dbg[wv * 4 + 3] = dbg_long;
+            atomicAdd(&g_stats[TH_GROUND], th[0]); atomicAdd(&g_stats[TH_LARGE_SETUP], th[1]); atomicAdd(&g_stats[TH_WALK], th[2]); atomicAdd(&g_stats[TH_SCAN], th[3]);
             atomicAdd(&g_stats[ST_SPARE0], dbg_thin_cyc); atomicAdd(&g_stats[ST_SPARE1], dbg_thin_closest); atomicAdd(&g_stats[ST_SPARE2], dbg_thin1_cyc); atomicAdd(&g_stats[ST_SPARE3], (unsigned long long)dbg_thin1_iters); atomicAdd(&g_stats[ST_SPARE4], (unsigned long long)dbg_thin_iters);
         }
         atomicAdd(&g_stats[ST_SAMPLES], 1ull);

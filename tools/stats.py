@@ -66,6 +66,10 @@ print("wave-cycles (summed over waves): total %.0fM, closest-hit %.1f%% (fast pa
 print("  inside the fast path: large spheres + set-up %.1f%% of total wave-cycles" % (100 * raw[33] / cyc[0]))
 print("  phase B (roots + offer) of the per-lane walk: %.1f%% of total wave-cycles" % (100 * raw[34] / cyc[0]))
 
+if sp[3]:
+    n12 = sp[3]
+    print("iterations of thin waves with <= 2 live lanes: %.1f k cycles each = ground %.1f k + large spheres/set-up %.1f k + grid walk %.1f k + scan %.1f k + shade/loop %.1f k" % (
+        sp[2] / n12 / 1e3, raw[59] / n12 / 1e3, raw[60] / n12 / 1e3, raw[61] / n12 / 1e3, raw[62] / n12 / 1e3, (sp[2] - raw[59] - raw[60] - raw[61] - raw[62]) / n12 / 1e3))
 wp = ["ground", "large_k", "large_exact", "offer_node", "offer_raybox", "elig_fn", "elig_list", "setup", "A_col", "A_batch", "A_hold",
       "B_offer", "B_clip", "coop_chunk", "scan", "scatter", "sc_lambert", "sc_metal", "sc_dielectric", "rej_iter", "primary", "disk_iter", "sky", "end_pixel"]
 li = max(1, v["loop_iters_wave"])
