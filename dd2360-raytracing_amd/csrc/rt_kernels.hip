@@ -190,6 +190,32 @@ RT_DEV const RenderArgs* cold_args() {
 }
 
 RT_DEV float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// Minimum over the wave (HALF = false) or over each half-wave (HALF = true), in every lane of the wave / half.  DPP row shifts
+// and row broadcasts (~10 cycles a step) instead of six dependent ds_bpermute round trips (~100 cycles each): the cooperative
+// paths run in waves with nothing else to do while a reduction is in flight.
+template <bool HALF>
+RT_DEV float group_min(float v) {
+    const int inf = 0x7f800000;
+    int x = __float_as_int(v);
+#define RT_DPP_MIN(ctrl, rmask) x = __float_as_int(fminf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(inf, x, ctrl, rmask, 0xf, false))))
+    RT_DPP_MIN(0x111, 0xf);     // row_shr:1
+    RT_DPP_MIN(0x112, 0xf);     // row_shr:2
+    RT_DPP_MIN(0x114, 0xf);     // row_shr:4
+    RT_DPP_MIN(0x118, 0xf);     // row_shr:8   -> lane 15 of each row of 16 holds the row's minimum
+    RT_DPP_MIN(0x142, 0xa);     // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold their half's minimum
+    if (!HALF) RT_DPP_MIN(0x143, 0xc);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+#undef RT_DPP_MIN
+    const int hi = __builtin_amdgcn_readlane(x, 63);
+    if (HALF) { const int lo = __builtin_amdgcn_readlane(x, 31); return __int_as_float((threadIdx.x & 32) ? hi : lo); }
+    return __int_as_float(hi);
+}
+RT_DEV int wave_min_int(int x) {                              // the same for int32, whole wave
+    const int big = 0x7fffffff;
+#define RT_DPP_MIN(ctrl, rmask) x = min(x, __builtin_amdgcn_update_dpp(big, x, ctrl, rmask, 0xf, false))
+    RT_DPP_MIN(0x111, 0xf); RT_DPP_MIN(0x112, 0xf); RT_DPP_MIN(0x114, 0xf); RT_DPP_MIN(0x118, 0xf); RT_DPP_MIN(0x142, 0xa); RT_DPP_MIN(0x143, 0xc);
+#undef RT_DPP_MIN
+    return __builtin_amdgcn_readlane(x, 63);
+}
 RT_DEV int bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
 // sphere::hit reduced to "which t would this sphere offer": the near root if it is > t_min, else the far root if that
@@ -238,10 +264,8 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
                     if (cand < my_t) { my_t = cand; my_k = k; }
                 }
             }
-            float mn = my_t;
-            for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
-            int km = (my_t == mn && my_k != 0x7fffffff) ? my_k : 0x7fffffff;
-            for (int off = 32; off > 0; off >>= 1) km = min(km, __shfl_xor(km, off));
+            const float mn = group_min<false>(my_t);
+            const int km = wave_min_int((my_t == mn && my_k != 0x7fffffff) ? my_k : 0x7fffffff);
             if (lane == L && km != 0x7fffffff) { closest = mn; best = S.list_id[km]; }
         }
         return;
@@ -515,8 +539,7 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                     }
                     // an equal t from a different tree sphere than the current best: the visit order would decide
                     if (__ballot(want && cand == bt && id != bi && bi > 0) != 0ull) tieL = true;
-                    float mn = elig ? cand : __builtin_inff();
-                    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+                    const float mn = group_min<false>(elig ? cand : __builtin_inff());
                     if (mn < bt) {
                         const unsigned long long mm = __ballot(elig && cand == mn);
                         const int wid = bcast(id, __ffsll((long long)mm) - 1);
@@ -620,8 +643,7 @@ RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, f
                 }
                 // an equal t from a different tree sphere than the current best: the visit order would decide
                 if ((__ballot(want && cand == bt && id != bi && bi > 0) & gmask) != 0ull) tieL = true;
-                float mn = elig ? cand : __builtin_inff();
-                for (int off = 16; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+                const float mn = group_min<true>(elig ? cand : __builtin_inff());
                 const unsigned long long mm = __ballot(elig && cand == mn) & gmask;         // (empty when mn is +inf)
                 const int wl = mm != 0ull ? __ffsll((long long)mm) - 1 : lane;
                 const int wid = __shfl(id, wl);
