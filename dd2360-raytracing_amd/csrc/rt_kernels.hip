@@ -481,7 +481,7 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
             int eb = 0, cnt = 0;
             if (lane < ncol) { int e1; column_range(A, Q, Q.i + lane * stp, eb, e1); cnt = e1 - eb; }
             int incl = cnt;                                  // inclusive prefix over lanes 0..7
-            { int t = __shfl_up(incl, 1); if (lane >= 1) incl += t; t = __shfl_up(incl, 2); if (lane >= 2) incl += t; t = __shfl_up(incl, 4); if (lane >= 4) incl += t; }
+            { incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); }   // row_shr:1,2,4 (the 8 lanes sit in one row of 16)
             const int total = bcast(incl, 7);
             for (int base = 0; base < total; base += 64) {
                 const int jdx = base + lane;
@@ -585,7 +585,7 @@ RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, f
         int eb = 0, cnt = 0;
         if (sl < ncol) { int e1; column_range(A, Q, Q.i + sl * stp, eb, e1); cnt = e1 - eb; }
         int incl = cnt;                                      // inclusive prefix over sub-lanes 0..7 of the half
-        { int t = __shfl_up(incl, 1); if (sl >= 1) incl += t; t = __shfl_up(incl, 2); if (sl >= 2) incl += t; t = __shfl_up(incl, 4); if (sl >= 4) incl += t; }
+        { incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); }   // row_shr:1,2,4 (the 8 lanes sit in one row of 16)
         const int total = __shfl(incl, gb + 7);
         int inc_m[8], cnt_m[8], eb_m[8];
 #pragma unroll
