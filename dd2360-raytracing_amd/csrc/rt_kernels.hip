@@ -48,7 +48,7 @@ namespace rt {
 #define RT_THIN_CAP_DEN 4   // at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
 #endif
 #ifndef RT_COOP_MAX
-#define RT_COOP_MAX 4
+#define RT_COOP_MAX 8
 #endif
 // phase-A iterations a wave spends on its lanes' walks per bounce iteration before unfinished walks are postponed (0 = no cap)
 #ifndef RT_WALK_CAP
