@@ -190,10 +190,10 @@ RT_DEV const RenderArgs* cold_args() {
 }
 
 RT_DEV float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-// Minimum over the wave (HALF = false) or over each half-wave (HALF = true), in every lane of the wave / half.  DPP row shifts
-// and row broadcasts (~10 cycles a step) instead of six dependent ds_bpermute round trips (~100 cycles each): the cooperative
-// paths run in waves with nothing else to do while a reduction is in flight.
-template <bool HALF>
+// Minimum over each group of LG = 64, 32 or 16 consecutive lanes, in every lane of the group.  DPP row shifts and row
+// broadcasts (~10 cycles a step) instead of dependent ds_bpermute round trips (~100 cycles each): the cooperative paths run in
+// waves with nothing else to do while a reduction is in flight.
+template <int LG>
 RT_DEV float group_min(float v) {
     const int inf = 0x7f800000;
     int x = __float_as_int(v);
@@ -202,12 +202,16 @@ RT_DEV float group_min(float v) {
     RT_DPP_MIN(0x112, 0xf);     // row_shr:2
     RT_DPP_MIN(0x114, 0xf);     // row_shr:4
     RT_DPP_MIN(0x118, 0xf);     // row_shr:8   -> lane 15 of each row of 16 holds the row's minimum
-    RT_DPP_MIN(0x142, 0xa);     // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold their half's minimum
-    if (!HALF) RT_DPP_MIN(0x143, 0xc);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+    if (LG >= 32) RT_DPP_MIN(0x142, 0xa);     // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold their half's minimum
+    if (LG >= 64) RT_DPP_MIN(0x143, 0xc);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
 #undef RT_DPP_MIN
-    const int hi = __builtin_amdgcn_readlane(x, 63);
-    if (HALF) { const int lo = __builtin_amdgcn_readlane(x, 31); return __int_as_float((threadIdx.x & 32) ? hi : lo); }
-    return __int_as_float(hi);
+    const int q3 = __builtin_amdgcn_readlane(x, 63);
+    if (LG == 64) return __int_as_float(q3);
+    const int q1 = __builtin_amdgcn_readlane(x, 31);
+    if (LG == 32) return __int_as_float((threadIdx.x & 32) ? q3 : q1);
+    const int q0 = __builtin_amdgcn_readlane(x, 15), q2 = __builtin_amdgcn_readlane(x, 47);
+    const int g = (threadIdx.x >> 4) & 3;
+    return __int_as_float(g == 0 ? q0 : g == 1 ? q1 : g == 2 ? q2 : q3);
 }
 RT_DEV int wave_min_int(int x) {                              // the same for int32, whole wave
     const int big = 0x7fffffff;
@@ -264,7 +268,7 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
                     if (cand < my_t) { my_t = cand; my_k = k; }
                 }
             }
-            const float mn = group_min<false>(my_t);
+            const float mn = group_min<64>(my_t);
             const int km = wave_min_int((my_t == mn && my_k != 0x7fffffff) ? my_k : 0x7fffffff);
             if (lane == L && km != 0x7fffffff) { closest = mn; best = S.list_id[km]; }
         }
@@ -539,7 +543,7 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
                     }
                     // an equal t from a different tree sphere than the current best: the visit order would decide
                     if (__ballot(want && cand == bt && id != bi && bi > 0) != 0ull) tieL = true;
-                    const float mn = group_min<false>(elig ? cand : __builtin_inff());
+                    const float mn = group_min<64>(elig ? cand : __builtin_inff());
                     if (mn < bt) {
                         const unsigned long long mm = __ballot(elig && cand == mn);
                         const int wid = bcast(id, __ffsll((long long)mm) - 1);
@@ -556,15 +560,18 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 }
 
 
-// The cooperative walk for TWO rays at once, one per half-wave (a thin wave usually holds two chains: RT_LONG_PER_WAVE, and
-// the walk is half of the time a bounce takes there).  Same steps as walk_coop with 32 lanes per ray: up to 8 columns per
-// chunk, entries spread over the half's lanes, candidates resolved in parallel, minimum over the half.  Reads across lanes
-// are ds_bpermute (the source lane differs between the halves); ballots are masked with the half's lanes.
-RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int L0, int L1, float& best_t, int& best, bool& tie STAT_ARG) {
+// The cooperative walk for G = 2 or 4 rays at once, one per group of 64/G lanes (a thin wave usually holds two chains:
+// RT_LONG_PER_WAVE, and the walk is half of the time a bounce takes there).  Same steps as walk_coop with fewer lanes per ray:
+// up to 8 columns per chunk, entries spread over the group's lanes, candidates resolved in parallel, minimum over the group.
+// Reads across lanes are ds_bpermute (the source lane differs between the groups); ballots are masked with the group's lanes.
+// Rays live in lanes L0..L3; groups n_rays.. idle.
+template <int G>
+RT_DEV void walk_coop_g(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int n_rays, int L0, int L1, int L2, int L3, float& best_t, int& best, bool& tie STAT_ARG) {
     const DevAccel& A = T.acc;
-    const int lane = threadIdx.x & 63, g = lane >> 5, sl = lane & 31, gb = lane & 32;
-    const int Ls = g ? L1 : L0;                               // this half's ray lives in lane Ls
-    const unsigned long long gmask = g ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    constexpr int LG = 64 / G;
+    const int lane = threadIdx.x & 63, g = lane / LG, sl = lane & (LG - 1), gb = lane & ~(LG - 1);
+    const int Ls = g == 0 ? L0 : g == 1 ? L1 : g == 2 ? L2 : L3;           // this group's ray lives in lane Ls
+    const unsigned long long gmask = (LG == 32 ? 0xffffffffull : 0xffffull) << gb;
     RayF q;
     q.o.x = __shfl(r.o.x, Ls); q.o.y = __shfl(r.o.y, Ls); q.o.z = __shfl(r.o.z, Ls);
     q.d.x = __shfl(r.d.x, Ls); q.d.y = __shfl(r.d.y, Ls); q.d.z = __shfl(r.d.z, Ls);
@@ -577,7 +584,7 @@ RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, f
     bool tieL = false;
     const int stp = Q.fwd ? 1 : -1;
     const float ra = __builtin_amdgcn_rcpf(qa);
-    bool go = Q.i != Q.iend;                                  // uniform within a half
+    bool go = g < n_rays && Q.i != Q.iend;                    // uniform within a group
     while (__ballot(go) != 0ull) {
         STAT(st, ST_A_ITERS_WAVE, 1); WPASS(WP_COOP_CHUNK);
         const int left = go ? (Q.fwd ? (Q.iend - Q.i) : (Q.i - Q.iend)) : 0;
@@ -590,9 +597,10 @@ RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, f
         int inc_m[8], cnt_m[8], eb_m[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) { inc_m[m] = __shfl(incl, gb + m); cnt_m[m] = __shfl(cnt, gb + m); eb_m[m] = __shfl(eb, gb + m); }
-        const int t_other = __shfl(total, lane ^ 32);
-        const int t_any = total > t_other ? total : t_other;  // wave-uniform
-        for (int base = 0; base < t_any; base += 32) {
+        int t_any = 0;                                        // wave-uniform
+#pragma unroll
+        for (int k = 0; k < G; ++k) { const int tk = __builtin_amdgcn_readlane(total, k * LG); t_any = tk > t_any ? tk : t_any; }
+        for (int base = 0; base < t_any; base += LG) {
             const int jdx = base + sl;
             const bool have = jdx < total;
             int e = 0;
@@ -643,7 +651,7 @@ RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, f
                 }
                 // an equal t from a different tree sphere than the current best: the visit order would decide
                 if ((__ballot(want && cand == bt && id != bi && bi > 0) & gmask) != 0ull) tieL = true;
-                const float mn = group_min<true>(elig ? cand : __builtin_inff());
+                const float mn = group_min<LG>(elig ? cand : __builtin_inff());
                 const unsigned long long mm = __ballot(elig && cand == mn) & gmask;         // (empty when mn is +inf)
                 const int wl = mm != 0ull ? __ffsll((long long)mm) - 1 : lane;
                 const int wid = __shfl(id, wl);
@@ -657,11 +665,12 @@ RT_DEV void walk_coop2(const DevTree& T, const float4* s_nodes, const RayF& r, f
             go = Q.i != Q.iend;
         }
     }
-    const float bt0 = __shfl(bt, 0), bt1 = __shfl(bt, 32);
-    const int bi0 = __shfl(bi, 0), bi1 = __shfl(bi, 32);
-    const int ti0 = __shfl((int)tieL, 0), ti1 = __shfl((int)tieL, 32);
-    if (lane == L0) { best_t = bt0; best = bi0; tie = tie || (ti0 != 0); W.walking = false; }
-    if (lane == L1) { best_t = bt1; best = bi1; tie = tie || (ti1 != 0); W.walking = false; }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const float btk = bcast(bt, k * LG); const int bik = bcast(bi, k * LG), tik = bcast((int)tieL, k * LG);
+        const int Lk = k == 0 ? L0 : k == 1 ? L1 : k == 2 ? L2 : L3;
+        if (k < n_rays && lane == Lk) { best_t = btk; best = bik; tie = tie || (tik != 0); W.walking = false; }
+    }
 }
 
 // Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
@@ -887,13 +896,18 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         // the cooperative walk starts at a column boundary: not while a lane has a partly tested column
         const bool coop = nw > 0 && nw <= RT_COOP_MAX && __ballot(walker && ts.e < ts.e_end) == 0ull;
         if (coop) {
-            // two rays at a time (one per half-wave), a last odd one with all 64 lanes
+            // four or two rays at a time (one per quarter- / half-wave), a single one with all 64 lanes
             const int lane_ = threadIdx.x & 63;
             unsigned long long todo = __ballot(walker && ts.W.walking);
-            while (__popcll(todo) >= 2) {
-                const int L0 = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
-                const int L1 = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
-                walk_coop2(T, s_nodes, r, a, ts.W, L0, L1, closest, best, ts.tie STAT_PASS);
+            auto pop = [&]() -> int { const int L = __ffsll((long long)todo) - 1; todo &= todo - 1ull; return L; };
+            while (__popcll(todo) >= 3) {                    // four (or three) at a time on quarter-waves
+                const int n = __popcll(todo) >= 4 ? 4 : 3;
+                const int L0 = pop(), L1 = pop(), L2 = pop(), L3 = n == 4 ? pop() : L2;
+                walk_coop_g<4>(T, s_nodes, r, a, ts.W, n, L0, L1, L2, L3, closest, best, ts.tie STAT_PASS);
+            }
+            if (__popcll(todo) == 2) {
+                const int L0 = pop(), L1 = pop();
+                walk_coop_g<2>(T, s_nodes, r, a, ts.W, 2, L0, L1, L1, L1, closest, best, ts.tie STAT_PASS);
             }
             if (todo != 0ull) walk_coop(T, s_nodes, r, a, ts.W, lane_ == __ffsll((long long)todo) - 1, closest, best, ts.tie STAT_PASS);
         }
