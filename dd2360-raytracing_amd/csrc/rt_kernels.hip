@@ -76,7 +76,7 @@ namespace rt {
 #endif
 // long chains started per thin wave
 #ifndef RT_LONG_PER_WAVE
-#define RT_LONG_PER_WAVE 2
+#define RT_LONG_PER_WAVE 4
 #endif
 // list path: rays are scanned cooperatively (lanes = spheres) while live_rays * RT_LIST_COOP_COST <= list size
 #ifndef RT_LIST_COOP_COST
