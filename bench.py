@@ -170,6 +170,14 @@ def main():
     value = samples_step * args.steps / dt / 1e6
 
     if rank == 0:
+        # the render kernel that ran (rt_kernels.hip launch_render: sparse grids take the variant with grouped cooperative walks)
+        if cfg.get("fp16"):
+            kernel_name = "k_render_h<%s,0>" % ("true" if cfg["octree"] else "false")
+        elif cfg["octree"]:
+            ai = O.accel_info()
+            kernel_name = "k_render<true,0,%d>" % (4 if ai["grid_entries"] <= 8 * ai["grid_dim"] ** 2 else 1)
+        else:
+            kernel_name = "k_render<false,0,1>"
         flops_launch = cfg["flops_per_sample"] * local_samples
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         traffic = None
@@ -187,7 +195,7 @@ def main():
                        % (cfg["name"], nx, ny, spp, cfg["spheres"], "on" if cfg["octree"] else "off", cfg["spl"], "USE_FP16" if cfg.get("fp16") else "fp32",
                           "" if world == 1 else "; frame grown to %d x 960000 px, 8x8 tiles round-robin over %d GPUs, one RCCL gather" % (world, world)),
                        "timed_region": "render_init + render (+ gather + assemble when n_gpus>1), scene resident in HBM"},
-            "roofline": {"bound": "valu", "kernel": "%s<%s,0>" % ("k_render_h" if cfg.get("fp16") else "k_render", "true" if cfg["octree"] else "false"),
+            "roofline": {"bound": "valu", "kernel": kernel_name,
                          "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "render_call_ms": round(call_ms, 4), "flops_per_sample": cfg["flops_per_sample"],

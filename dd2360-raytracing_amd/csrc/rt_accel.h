@@ -181,6 +181,9 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     p.ylo = (float)(ylo - 1e-4); p.yhi = (float)(yhi + 1e-4); p.rmax = (float)(rmax + 1e-4);
     p.zone2 = (float)(kZone * kZone);
     p.enabled = 1;
+    // rays side by side in the cooperative walk pay off while a chunk of 8 columns is a handful of entries (C3: 3.6 per cell);
+    // on dense grids (C5: N = 100 000, ~40 per cell) an uneven pair of rays costs twice the longer one
+    p.coop_groups = (double)total <= 8.0 * (double)ncell ? 4 : 1;
 }
 
 } // namespace rt

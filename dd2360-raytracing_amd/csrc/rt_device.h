@@ -59,6 +59,7 @@ struct DevAccel {
     float rmax;                // largest inflated radius R' of a grid sphere
     float zone2;               // fast path only for ray origins with |o - (0,1,0)|^2 <= zone2
     int32_t enabled;
+    int32_t coop_groups;       // cooperative walk: up to this many rays side by side (4 on sparse grids, 1 on dense ones)
 };
 
 struct DevTree {

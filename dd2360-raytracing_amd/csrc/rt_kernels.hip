@@ -594,18 +594,19 @@ RT_DEV void walk_coop_g(const DevTree& T, const float4* s_nodes, const RayF& r, 
         int incl = cnt;                                      // inclusive prefix over sub-lanes 0..7 of the half
         { incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); }   // row_shr:1,2,4 (the 8 lanes sit in one row of 16)
         const int total = __shfl(incl, gb + 7);
-        int inc_m[8], cnt_m[8], eb_m[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) { inc_m[m] = __shfl(incl, gb + m); cnt_m[m] = __shfl(cnt, gb + m); eb_m[m] = __shfl(eb, gb + m); }
+        const int start = incl - cnt;                          // first position of this column's entries in the chunk
         int t_any = 0;                                        // wave-uniform
 #pragma unroll
         for (int k = 0; k < G; ++k) { const int tk = __builtin_amdgcn_readlane(total, k * LG); t_any = tk > t_any ? tk : t_any; }
         for (int base = 0; base < t_any; base += LG) {
             const int jdx = base + sl;
             const bool have = jdx < total;
-            int e = 0;
+            int e = 0;                                          // (fetched per pass, not hoisted: registers decide the occupancy)
 #pragma unroll
-            for (int m = 0; m < 8; ++m) if (jdx >= inc_m[m] - cnt_m[m] && jdx < inc_m[m]) e = eb_m[m] + (jdx - (inc_m[m] - cnt_m[m]));
+            for (int m = 0; m < 8; ++m) {
+                const int st_m = __shfl(start, gb + m), in_m = __shfl(incl, gb + m), eb_m = __shfl(eb, gb + m);
+                if (jdx >= st_m && jdx < in_m) e = eb_m + (jdx - st_m);
+            }
             float cand = __builtin_inff();
             bool want = false;
             float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
@@ -835,6 +836,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
 // shade and start new rays — the wave no longer waits for its longest walk.  `closest`/`best` persist with the caller.
 struct TreeState { Walk W; int e, e_end; float g_t; int g_id; bool tie, pending; };
 
+template <int COOPG>
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best, TreeState& ts STAT_ARG) {
     const bool fresh = live && !ts.pending;
     STAT(st, ST_RAYS, fresh ? 1 : 0);
@@ -900,15 +902,19 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             const int lane_ = threadIdx.x & 63;
             unsigned long long todo = __ballot(walker && ts.W.walking);
             auto pop = [&]() -> int { const int L = __ffsll((long long)todo) - 1; todo &= todo - 1ull; return L; };
-            while (__popcll(todo) >= 3) {                    // four (or three) at a time on quarter-waves
+            // (COOPG = 1 for dense grids, chosen at launch from DevAccel::coop_groups: groups share the wave's lanes evenly, so
+            // with hundreds of entries per chunk an uneven pair takes 2 x max instead of the sum — and the group code needs
+            // 142 VGPRs, 3 waves/SIMD, where the plain kernel runs 4, which is what a dense scene's long walks want)
+            while (COOPG >= 4 && __popcll(todo) >= 3) {                    // four (or three) at a time on quarter-waves
                 const int n = __popcll(todo) >= 4 ? 4 : 3;
                 const int L0 = pop(), L1 = pop(), L2 = pop(), L3 = n == 4 ? pop() : L2;
                 walk_coop_g<4>(T, s_nodes, r, a, ts.W, n, L0, L1, L2, L3, closest, best, ts.tie STAT_PASS);
             }
-            if (__popcll(todo) == 2) {
+            if (COOPG >= 2 && __popcll(todo) == 2) {
                 const int L0 = pop(), L1 = pop();
                 walk_coop_g<2>(T, s_nodes, r, a, ts.W, 2, L0, L1, L1, L1, closest, best, ts.tie STAT_PASS);
             }
+            while (__popcll(todo) > 1) { const int L = pop(); walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS); }
             if (todo != 0ull) walk_coop(T, s_nodes, r, a, ts.W, lane_ == __ffsll((long long)todo) - 1, closest, best, ts.tie STAT_PASS);
         }
         else if (walker) walk_lanes(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
 // a wave holding a long pixel stops refilling its other lanes ("thin" wave, raised issue priority) until that pixel is
 // finished, then resumes.  A global counter caps the
 // number of thin waves at a quarter of the grid, so a scene made of long pixels only keeps its throughput.
-template <bool TREE, int MODE>
+template <bool TREE, int MODE, int COOPG>
 __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
     if (TREE) {
@@ -1244,7 +1250,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         const unsigned long long c4_ = st.cyc[4], c5_ = st.cyc[5], c1_ = st.cyc[1], c3_ = st.cyc[3];
         const bool thin12 = thin && __popcll(__ballot(live)) <= 2;
 #endif
-        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
+        if (TREE) closest_tree<COOPG>(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
 #ifdef RT_STATS
         const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0; if (thin) dbg_thin_closest += tC1 - tC0;
@@ -1365,7 +1371,7 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     while (__ballot(live) != 0ull) {
         const float a = dot3(r.d, r.d);
         if (!TREE) { closest = FLT_MAX; best = -1; }
-        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
+        if (TREE) closest_tree<1>(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
         if (live && !(TREE && ts.pending)) {
             ++bounces;
@@ -1449,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_trace(RenderArgs A, const float* rays, 
         TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
         ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
         bool act = live;
-        do { closest_tree(S, T, s_nodes, r, a, act, closest, best, ts STAT_PASS); act = live && ts.pending; } while (__ballot(act) != 0ull);
+        do { closest_tree<1>(S, T, s_nodes, r, a, act, closest, best, ts STAT_PASS); act = live && ts.pending; } while (__ballot(act) != 0ull);
     } else closest_list(S, r, a, live, closest, best);
     if (!live) return;
     rt_hit_record h;
@@ -1516,10 +1522,10 @@ hipError_t RT_LIST_FN(launch_tile_cost)(const RenderArgs& A, unsigned blocks, in
 }
 hipError_t RT_LIST_FN(launch_render)(const RenderArgs& A, int mode, hipStream_t st) {
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
-    const unsigned cap = mode == 0 ? resident_blocks(k_render<false, 0>, 0) : resident_blocks(k_render<false, 1>, 0);
+    const unsigned cap = mode == 0 ? resident_blocks(k_render<false, 0, 1>, 0) : resident_blocks(k_render<false, 1, 1>, 0);
     const unsigned blocks = need < cap ? need : cap;
-    if (mode == 0) hipLaunchKernelGGL((k_render<false, 0>), dim3(blocks), dim3(256), 0, st, A);
-    else hipLaunchKernelGGL((k_render<false, 1>), dim3(blocks), dim3(256), 0, st, A);
+    if (mode == 0) hipLaunchKernelGGL((k_render<false, 0, 1>), dim3(blocks), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_render<false, 1, 1>), dim3(blocks), dim3(256), 0, st, A);
     return hipGetLastError();
 }
 hipError_t RT_LIST_FN(launch_trace)(const RenderArgs& A, unsigned blocks, const float* rays, long long n, rt_hit_record* out, hipStream_t st) {
@@ -1548,10 +1554,13 @@ hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t s
     if (!tree) return launch_render_list(A, mode, st);
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
     const size_t lds = (size_t)A.tree.n_nodes * sizeof(DevNode);
-    const unsigned cap = mode == 0 ? resident_blocks(k_render<true, 0>, lds) : resident_blocks(k_render<true, 1>, lds);
+    // sparse grids: the variant whose cooperative walk serves up to four rays side by side (rt_accel.h: coop_groups)
+    const bool groups = mode == 0 && A.tree.acc.enabled && A.tree.acc.coop_groups >= 4;
+    const unsigned cap = groups ? resident_blocks(k_render<true, 0, 4>, lds) : mode == 0 ? resident_blocks(k_render<true, 0, 1>, lds) : resident_blocks(k_render<true, 1, 1>, lds);
     const unsigned blocks = need < cap ? need : cap;
-    if (mode == 0) hipLaunchKernelGGL((k_render<true, 0>), dim3(blocks), dim3(256), lds, st, A);
-    else hipLaunchKernelGGL((k_render<true, 1>), dim3(blocks), dim3(256), lds, st, A);
+    if (groups) hipLaunchKernelGGL((k_render<true, 0, 4>), dim3(blocks), dim3(256), lds, st, A);
+    else if (mode == 0) hipLaunchKernelGGL((k_render<true, 0, 1>), dim3(blocks), dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_render<true, 1, 1>), dim3(blocks), dim3(256), lds, st, A);
     return hipGetLastError();
 }
 
