@@ -28,6 +28,8 @@ CONFIGS = {
     "c4": dict(name="C4", nx=1200, ny=800, spp=64, spheres=10000, octree=True, spl=32, flops_per_sample=9.8e3, fp16=True),
 }
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate, spec
+PEAK_UNFUSED_TOPS = 39.3              # 256 CUs x 64 lanes x 2.4 GHz, one unfused fp32 op per lane and cycle — the parity
+                                      # mode's own ceiling (no FMA contraction, no packed fp32); frac_unfused is measured against it
 PEAK_HBM_GBS = 8000.0
 
 
@@ -198,6 +200,7 @@ def main():
             "roofline": {"bound": "valu", "kernel": kernel_name,
                          "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
+                         "frac_unfused": round(achieved / PEAK_UNFUSED_TOPS, 5), "peak_unfused": PEAK_UNFUSED_TOPS,
                          "kernel_ms": round(kernel_ms, 4), "render_call_ms": round(call_ms, 4), "flops_per_sample": cfg["flops_per_sample"],
                          "note": "algorithmic unfused flops of the reference's visit set (SURVEY 8d) / device time of the render kernel "
                                  "(HIP events on its stream, last <=64 launches); render_call_ms adds the scheduling pre-pass; "
