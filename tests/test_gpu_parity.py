@@ -206,9 +206,14 @@ def test_full_size_properties_c3(rt, cuda):
     finite = got[np.isfinite(got)]
     assert finite.min() >= 0.0 and finite.max() <= 1.0 and finite.size > 0.99 * got.size
     S = OracleScene(n, nx, ny, use_octree=True, spl=spl)
-    for row in (3, 250, 431, 797):
-        ref, _ = S.render(ns, row0=row, rows=1, nthreads=1)
+    # rows 316/317 hold the frame's longest chains (crevices: 2500 bounces per pixel) — the pixels that travel through the
+    # thin-wave / cooperative-walk machinery of the render kernel
+    for row in (3, 100, 250, 316, 317, 431, 600, 797):
+        ref, _ = S.render(ns, row0=row, rows=1, nthreads=4)
         assert np.array_equal(bits(got[row]), bits(ref[0])), "row %d differs" % row
+    st_host = st.cpu().numpy().view(np.uint32).reshape(-1, 12)
+    _, st_ref = S.render(ns, row0=316, rows=2, nthreads=4)
+    assert np.array_equal(st_host[316 * nx: 318 * nx, :6], st_ref[:, :6])          # RNG state written back (main.cu:110)
     nparts = 4
     per = rt.part_pixels(nx, ny, rt.Partition(0, nparts))
     parts = torch.zeros(nparts * per * 3, dtype=torch.float32, device="cuda")
