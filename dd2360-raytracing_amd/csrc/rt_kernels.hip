@@ -6,9 +6,12 @@
 // (material.h:55-113) and camera::get_ray (camera.h:45-49).
 //
 // Shape:
-//   * one lane = one pixel (the per-pixel XORWOW stream is strictly serial), one wave64 = one 8x8 pixel tile;
+//   * one lane = one pixel (the per-pixel XORWOW stream is strictly serial); persistent waves pull pixels from a global
+//     queue (one pixel position of 64 different tiles per wave: long chains cluster), most expensive tiles first;
 //   * the reference's `for sample { for bounce {..} }` nest is flattened into ONE loop per lane: a lane whose path
 //     ended starts its next sample at once instead of idling until the slowest path of the wave finishes;
+//   * octree on: candidates come from an exact culling grid (rt_accel.h), the reference's traversal is the fallback;
+//     waves holding long pixel chains stop refilling ("thin") and resolve their few rays cooperatively, lanes = spheres;
 //   * no virtual calls, no device heap, no recursion: materials are a tag + 4 floats, the octree is a pre-order
 //     node array with skip links staged in LDS, bucket contents are pre-gathered (centre, r^2) float4 streams;
 //   * hitable_list path: the sphere index is wave-uniform, so sphere data comes through scalar loads (SGPR operands).
@@ -43,10 +46,11 @@ namespace rt {
 #ifndef RT_LONG_RATE
 #define RT_LONG_RATE 20
 #endif
-// waves with at most this many rays on the fast path walk the grid cooperatively (all lanes on one ray at a time)
+// at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
 #ifndef RT_THIN_CAP_DEN
-#define RT_THIN_CAP_DEN 4   // at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
+#define RT_THIN_CAP_DEN 4
 #endif
+// waves with at most this many rays on the fast path walk the grid cooperatively (lanes = spheres; 1, 2 or 4 rays at a time)
 #ifndef RT_COOP_MAX
 #define RT_COOP_MAX 8
 #endif
@@ -54,7 +58,6 @@ namespace rt {
 #ifndef RT_WALK_CAP
 #define RT_WALK_CAP 0      // measured: capping costs more main-loop iterations than it saves walk steps (cap 2: +32 %, 4: +8 %, 6: +1 %)
 #endif
-// pilot classification: a pixel whose RT_PILOT_SAMPLES pilot samples total at least RT_PILOT_LONG bounces is started as a long chain
 // A per-lane walk returns once only 1/RT_QUORUM_DEN of the lanes that entered it are still walking (in waves that entered
 // with >= RT_QUORUM_MIN walkers): the stragglers keep their position (TreeState) and resume on the next call, together
 // with the new rays of the lanes that went on to shade.  Measured on C3: off 32.3 ms, 2: 31.8, 4: 31.2, 8: 30.6, 16: 31.1.
@@ -65,6 +68,7 @@ namespace rt {
 #define RT_QUORUM_MIN 16
 #endif
 
+// pilot classification: a pixel whose RT_PILOT_SAMPLES pilot samples total at least RT_PILOT_LONG bounces is started as a long chain
 #ifndef RT_PILOT_SAMPLES
 #define RT_PILOT_SAMPLES 2
 #endif
