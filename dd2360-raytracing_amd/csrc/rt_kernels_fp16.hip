@@ -96,31 +96,48 @@ RT_DEV void closest_list(const DevScene& S, const Ray& r, R a, R& closest, int& 
     if (best >= 0) best = S.list_id[best];
 }
 
+// hitTree (acceleration_structure.h:319-342) in two phases per round, so that the 64 rays of a wave do not wait for each
+// other at every level-3 node: (1) walk the tree — the visited set does not depend on the hits (traverseTree prunes by the
+// slab test only) — and note the bucket ranges of up to kRanges visited non-empty nodes per lane in LDS; (2) scan them as ONE
+// flat sequence of sphere tests per lane, in the reference's order (nodes in traversal order, entries in bucket order).
+// Walking and scanning in lock step per node ran at 14 % lane utilisation (every node a barrier for the whole wave).
+constexpr int kRanges = 24;                                   // nodes noted per lane and round (24 x 256 x 2 B of LDS)
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const Ray& r, R a, bool live, R& closest, int& best) {
     if (S.ground_valid) {
         int gb = -1;
         sphere_test(r, a, S.list_hot[0], 0, closest, gb);
         if (gb == 0) best = 0;
     }
+    unsigned short* noted = (unsigned short*)(s_nodes + T.n_nodes * 3) + threadIdx.x;      // noted[k * 256]: this lane's k-th visited non-empty node
     int e_best = -1;
     int node = live ? 0 : T.n_nodes;
     const int n_nodes = T.n_nodes;
     while (true) {
-        int e = 0, e_end = 0;
-        while (node < n_nodes) {
+        int nr = 0;
+        while (node < n_nodes && nr < kRanges) {
             const float4 n0 = s_nodes[node * 3 + 0];
             const float4 n1 = s_nodes[node * 3 + 1];
             const float4 n2 = s_nodes[node * 3 + 2];
             if (ray_box(r, n0, n1)) {
                 const int cnt = __float_as_int(n2.x);
                 node = node + 1;
-                if (cnt > 0) { e = __float_as_int(n1.w); e_end = e + cnt; break; }
+                if (cnt > 0) { noted[nr * 256] = (unsigned short)(node - 1); ++nr; }
             } else {
                 node = __float_as_int(n1.z);
             }
         }
-        if (e >= e_end) break;
-        for (; e < e_end; ++e) sphere_test(r, a, T.ent_hot[e], e, closest, e_best);
+        if (__ballot(nr > 0) == 0ull) break;
+        int k = 0, e = 0, e_end = 0;
+        while (true) {
+            if (e >= e_end && k < nr) {
+                const int nd = (int)noted[k * 256]; ++k;
+                e = __float_as_int(s_nodes[nd * 3 + 1].w); e_end = e + __float_as_int(s_nodes[nd * 3 + 2].x);
+            }
+            const bool has = e < e_end;
+            if (__ballot(has) == 0ull) break;
+            if (has) { sphere_test(r, a, T.ent_hot[e], e, closest, e_best); ++e; }
+        }
+        if (__ballot(node < n_nodes) == 0ull) break;
     }
     if (e_best >= 0) best = T.ent_id[e_best];
 }
@@ -367,7 +384,7 @@ static unsigned resident_blocks_h(const void* kernel, size_t lds) {
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
-    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) : 0;
+    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) + (size_t)h16::kRanges * 256 * sizeof(unsigned short) : 0;
     void (*k)(RenderArgs) = tree ? (mode == 0 ? h16::k_render_h<true, 0> : h16::k_render_h<true, 1>)
                                  : (mode == 0 ? h16::k_render_h<false, 0> : h16::k_render_h<false, 1>);
     const unsigned cap = resident_blocks_h((const void*)k, lds);
@@ -379,7 +396,7 @@ hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t
 hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) : 0;
+    const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) + (size_t)h16::kRanges * 256 * sizeof(unsigned short) : 0;
     if (tree) hipLaunchKernelGGL((h16::k_trace_h<true>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
     else hipLaunchKernelGGL((h16::k_trace_h<false>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
     return hipGetLastError();
