@@ -1121,7 +1121,8 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     int sample = 0, depth = 0;
     bool live = false;
 #ifdef RT_STATS
-    unsigned int pix_iters = 0, pix_steps = 0, steps_mark = 0;
+    unsigned int pix_iters = 0;
+    unsigned long long pix_t0 = 0;
 #endif
 
     // claim `slot` (skipping slots that fall outside the frame in edge tiles) and set the lane up for that pixel
@@ -1148,6 +1149,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             if (i < A.max_x && j < A.max_y && !taken) {
                 idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l;
                 live = true;
+#ifdef RT_STATS
+                pix_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 break;
             }
             slot = first_free + (long long)atomicAdd(A.queue, 1u);
@@ -1174,6 +1178,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
         idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
         live = true; iters = 0; is_long = true;
+#ifdef RT_STATS
+        pix_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const rt_rand_state* st = A.rand_state + idx;
         s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
         col = {0.0f, 0.0f, 0.0f}; att = {1.0f, 1.0f, 1.0f}; sample = 0; depth = 0;
@@ -1191,7 +1198,8 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             col.x *= k; col.y *= k; col.z *= k;
             fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
 #ifdef RT_STATS
-            fb[0] = (float)pix_iters; fb[1] = (float)pix_steps;      // diagnostic build: chain length instead of colour
+            // diagnostic build: chain length and end / start time (100 MHz ticks mod 2^24) instead of colour
+            fb[0] = (float)pix_iters; fb[1] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffffull); fb[2] = (float)(pix_t0 & 0xffffffull);
 #endif
         } else {
             if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
@@ -1285,9 +1293,6 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                         is_long = true;
                     }
                 } else {
-#ifdef RT_STATS
-                    pix_steps = st.c[ST_A_LANE_STEPS] - steps_mark; steps_mark = st.c[ST_A_LANE_STEPS];
-#endif
                     WPASS(WP_ENDPIX);
                     end_pixel();
 #ifdef RT_STATS

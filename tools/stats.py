@@ -36,15 +36,26 @@ print("waves %d; loop iterations by live lanes: >=56: %.3f  32-55: %.3f  8-31: %
 
 import numpy as np
 img = fb.cpu().numpy().reshape(ny, nx, 3)
-it, stp = img[:, :, 0], img[:, :, 1]
+it = img[:, :, 0]
 print("per-pixel loop iterations: mean %.1f  p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f" % (it.mean(), *np.percentile(it, [50, 90, 99, 99.9]), it.max()))
-print("per-pixel walk steps:      mean %.1f  p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f" % (stp.mean(), *np.percentile(stp, [50, 90, 99, 99.9]), stp.max()))
+tend, tstart = img[:, :, 1].astype(np.float64), img[:, :, 2].astype(np.float64)
+t0_ = tstart.min()
+tend = ((tend - t0_) % 2**24) / 1e5; tstart = ((tstart - t0_) % 2**24) / 1e5          # ms since the first pixel started
+T = tend.max()
+print("pixel timing: frame ends at %.2f ms; pixels ending in the last 2 ms: %d, last 1 ms: %d" % (T, (tend > T - 2).sum(), (tend > T - 1).sum()))
+late = tend > T - 1.5
+if late.any():
+    print("  those ending in the last 1.5 ms: started at ms p10 %.1f p50 %.1f p90 %.1f; iterations p10 %.0f p50 %.0f p90 %.0f; duration ms p50 %.1f" % (
+        *np.percentile(tstart[late], [10, 50, 90]), *np.percentile(it[late], [10, 50, 90]), np.percentile((tend - tstart)[late], 50)))
+for lo, hi in ((0, 200), (200, 400), (400, 800), (800, 1280), (1280, 4000)):
+    m = (it >= lo) & (it < hi)
+    if m.any():
+        print("  pixels with %4d-%4d iterations: %7d, start p50 %.1f p90 %.1f max %.1f ms; end p50 %.1f p99 %.1f max %.1f ms; us/iteration p50 %.1f" % (
+            lo, hi, m.sum(), *np.percentile(tstart[m], [50, 90, 100]), *np.percentile(tend[m], [50, 99, 100]), np.percentile(((tend - tstart)[m] / np.maximum(it[m], 1)) * 1e3, 50)))
 rows = it.mean(axis=1)
 print("row means of iterations (every 50 rows from bottom):", " ".join("%.0f" % rows[k] for k in range(0, ny, 50)))
-rows = stp.mean(axis=1)
-print("row means of walk steps (every 50 rows from bottom):", " ".join("%.0f" % rows[k] for k in range(0, ny, 50)))
 worst = np.argsort(it.ravel())[-5:]
-print("worst pixels (row, col, iters, steps):", [(int(w // nx), int(w % nx), int(it.ravel()[w]), int(stp.ravel()[w])) for w in worst])
+print("worst pixels (row, col, iters):", [(int(w // nx), int(w % nx), int(it.ravel()[w])) for w in worst])
 
 wb = (C.c_ulonglong * (8192 * 4))()
 L.rt_debug_waves.restype = C.c_int; L.rt_debug_waves.argtypes = [C.c_void_p]
