@@ -356,9 +356,9 @@ RT_DEV bool eligible(const float4* s_nodes, const RayF& r, float cand, int spher
 
 // Does the hit at `cand` lie inside the sphere's brick (rt_accel.h: the box of level-3 cells that ALL store the sphere, in
 // cell coordinates, margins included)?  Then it lies in a stored cell whose three float slab intervals contain the hit's t
-// (the hit point keeps 0.012 from the brick's outer faces, rounding moves an interval end by ~1e-5; inner faces are shared
+// (the hit point keeps 0.002 from the brick's outer faces, rounding moves an interval end by < 1e-5; inner faces are shared
 // planes, so the cells' intervals tile the brick's without gaps): that node passes the reference's slab test, and with it
-// its ancestors — no division needed.  Approximate arithmetic is fine here: the margins hold >= 5e-4.
+// its ancestors — no division needed.  Approximate arithmetic is fine here: its error is part of the 1e-5.
 RT_DEV bool in_brick(const RayF& r, float cand, const float4 blo, const float4 bhi) {
     const float ux = __builtin_fmaf(__builtin_fmaf(cand, r.d.x, r.o.x), 1.0f / 2.75f, 4.0f);
     const float uy = __builtin_fmaf(cand, r.d.y, r.o.y) * 4.0f;

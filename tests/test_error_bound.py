@@ -116,3 +116,36 @@ def test_walk_prefilter_never_rejects_an_acceptable_sphere():
             assert not (reject & acceptable).any()
     # the filter does something: most unacceptable boundary cases further than its margin are rejected
     assert (reject & ~acceptable).sum() > 0.2 * (~acceptable).sum()
+
+
+def test_brick_margin_puts_t_inside_the_float_slab_interval():
+    """Brick eligibility (rt_kernels.hip in_brick): if the kernel's hit point, in level-3 cell coordinates,
+    lies inside the brick bounds (margin 8e-4 cells in x/z, 8.5e-3 in y ~ 0.002 in distance), the hit's t lies inside the float
+    slab interval [fl(fl(X0-o)/d), fl(fl(X1-o)/d)] of intersect_ray_aabb (acceleration_structure.h:226-244) for that axis.
+    Adversarial: hit points placed within +-1e-4 of the margin line, origins in the near zone, |d| over five decades."""
+    rng = np.random.default_rng(21)
+    n = 2_000_000
+    for cell, org, scale, margin in ((2.75, -11.0, F(1.0 / 2.75), 8e-4), (0.25, 0.0, F(4.0), 8.5e-3)):
+        i0 = rng.integers(0, 8, n); i1 = np.minimum(7, i0 + rng.integers(0, 3, n))
+        X0 = (org + cell * i0).astype(F); X1 = (org + cell * (i1 + 1)).astype(F)          # exact in float32
+        o = rng.uniform(-25, 25, n).astype(F)
+        d = (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-3, 2, n)).astype(F)
+        # a hit point close to the margin line inside the lower or the upper face
+        side = rng.integers(0, 2, n)
+        target = np.where(side == 0, X0.astype(np.float64) + cell * margin, X1.astype(np.float64) - cell * margin) + rng.uniform(-1e-4, 1e-4, n)
+        t = ((target - o.astype(np.float64)) / d.astype(np.float64)).astype(F)
+        keep = t > F(0.001)
+        # kernel side: P = fma(t, d, o), u = fma(P, scale, 4) (x/z) or P * 4 (y)
+        P = (t.astype(np.float64) * d.astype(np.float64) + o.astype(np.float64)).astype(F)
+        u = (P.astype(np.float64) * float(scale) + (4.0 if cell == 2.75 else 0.0)).astype(F)
+        lo = (i0 + margin).astype(F); hi = (i1 + 1 - margin).astype(F)
+        inside = keep & (u > lo) & (u < hi)
+        # reference side
+        ta = ((X0 - o).astype(F) / d).astype(F); tb = ((X1 - o).astype(F) / d).astype(F)
+        tlo, thi = np.minimum(ta, tb), np.maximum(ta, tb)
+        assert inside.sum() > 0.15 * n
+        assert ((t >= tlo) & (t <= thi))[inside].all()
+        # ... and the margin is not vacuous: without it, points this close to the face do fall outside sometimes
+        bare = keep & (u > i0.astype(F)) & (u < (i1 + 1).astype(F))
+        near = np.abs(np.where(side == 0, P.astype(np.float64) - X0, X1 - P.astype(np.float64))) < 1e-5
+        assert bare.sum() >= inside.sum() and near.sum() == 0          # (the cases above keep >= 0.002 - 1e-4 from the faces)
