@@ -255,7 +255,7 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
     const float4* __restrict__ hot = S.list_hot;
     const int n = S.n_list;
     unsigned long long todo = __ballot(live);
-    if (__popcll(todo) * RT_LIST_COOP_COST <= n) {
+    if ((int)__popcll(todo) * RT_LIST_COOP_COST <= n) {
         const int lane = threadIdx.x & 63;
         while (todo != 0ull) {
             const int L = __ffsll((long long)todo) - 1;
@@ -738,7 +738,7 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
             const bool searching = walking && (p_e < 0);
             const unsigned long long ms = __ballot(searching), mp = __ballot(p_e >= 0);
             if (ms == 0ull || __popcll(mp) * RT_VOTE_NUM >= __popcll(ms) || (budget > 0 && used >= budget)) break;
-            if (RT_QUORUM_DEN > 0 && nw0 >= RT_QUORUM_MIN && (__popcll(ms) + __popcll(mp)) * RT_QUORUM_DEN <= nw0) { leave = true; break; }
+            if (RT_QUORUM_DEN > 0 && nw0 >= RT_QUORUM_MIN && (int)(__popcll(ms) + __popcll(mp)) * RT_QUORUM_DEN <= nw0) { leave = true; break; }
             ++used;
             STAT(st, ST_A_ITERS_WAVE, 1);
             if (searching) {
