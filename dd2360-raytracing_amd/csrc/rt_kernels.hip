@@ -73,10 +73,10 @@ namespace rt {
 #define RT_PILOT_SAMPLES 2
 #endif
 #ifndef RT_PILOT_LONG
-#define RT_PILOT_LONG 60
+#define RT_PILOT_LONG 50
 #endif
 #ifndef RT_PILOT_CAP
-#define RT_PILOT_CAP 50     // bounces after which a pilot sample is cut (the reference's depth limit: none)
+#define RT_PILOT_CAP 35     // bounces after which a pilot sample is cut (the pilot pass is as long as its longest chain; 50 = the reference's depth limit)
 #endif
 // long chains started per thin wave
 #ifndef RT_LONG_PER_WAVE
