@@ -1409,27 +1409,37 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
 
 RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (c > 7 ? 7 : c); }
 
-// one wave: stable counting sort of the tiles by cost class, descending
+// one block of 16 waves: stable counting sort of the tiles by cost class, descending (each wave takes a contiguous chunk)
 #ifndef RT_TU_LIST
-__global__ __launch_bounds__(64) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n) {
+    __shared__ int s_cnt[16][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long per = ((n + 15) / 16 + 63) / 64 * 64;          // tiles per wave, a multiple of 64
+    const long long lo = wave * per, hi = (lo + per < n) ? lo + per : n;
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long t = lane; t < n; t += 64) {
+    for (long long t = lo + lane; t < hi; t += 64) {
         const int c = cost_class(cost[t]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) cnt[k] += (c == k) ? 1 : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 8; ++k) {
         for (int off = 32; off > 0; off >>= 1) cnt[k] += __shfl_xor(cnt[k], off);
+        if (lane == 0) s_cnt[wave][k] = cnt[k];
+    }
+    __syncthreads();
     long long base[8];
     long long run = 0;
 #pragma unroll
-    for (int k = 7; k >= 0; --k) { base[k] = run; run += cnt[k]; }
+    for (int k = 7; k >= 0; --k) {                                 // class k: after every higher class, behind the earlier waves' share
+        long long before = 0, all = 0;
+        for (int w = 0; w < 16; ++w) { const int v = s_cnt[w][k]; all += v; if (w < wave) before += v; }
+        base[k] = run + before; run += all;
+    }
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (long long t0 = 0; t0 < n; t0 += 64) {
+    for (long long t0 = lo; t0 < hi; t0 += 64) {
         const long long t = t0 + lane;
-        const int c = t < n ? cost_class(cost[t]) : -1;
+        const int c = t < hi ? cost_class(cost[t]) : -1;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const unsigned long long m = __ballot(c == k);
@@ -1554,7 +1564,7 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     const unsigned blocks = (unsigned)((A.n_local_tiles + per_block - 1) / per_block);
     if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), (size_t)A.tree.n_nodes * sizeof(DevNode), st, A, cost, flags, long_list);
     else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, flags, long_list, st); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(64), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
     return hipGetLastError();
 }
 
