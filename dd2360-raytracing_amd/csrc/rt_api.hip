@@ -13,6 +13,7 @@
 
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
+hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st);
@@ -341,7 +342,7 @@ static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world*
     A.scene = world->dev;
     rt_world* wm = const_cast<rt_world*>(world);
     A.queue = wm->d_queue + (size_t)(wm->launches++ % kQueueSlots) * kQueueStride;
-    RT_TRY(hipMemsetAsync(A.queue, 0, 4 * sizeof(unsigned int), (hipStream_t)stream));
+    RT_TRY(launch_zero_counters(A.queue, 4, (hipStream_t)stream));
     if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
     else memset(&A.tree, 0, sizeof(A.tree));
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;

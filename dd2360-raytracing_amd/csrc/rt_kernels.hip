@@ -1505,6 +1505,14 @@ __global__ __launch_bounds__(256) void k_assemble(float* full, const float* part
 
 // ---------------------------------------------------------------------------------------------------- launchers
 #ifndef RT_TU_LIST
+// Zeroes the work counters of a launch.  A kernel of our own instead of hipMemsetAsync: captured into a hipGraph, the memset
+// node took effect on the first replay only (ROCm 7.2) — later replays found the queue exhausted and rendered nothing.
+__global__ void k_zero_counters(unsigned int* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0u; }
+hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, st, p, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st) {
     const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
     const long long tiles = (long long)tiles_x * tiles_y;

@@ -474,3 +474,49 @@ def test_reference_default_configuration(rt, cuda):
     for row in (0, 127, 402, 640, 799):
         ref, _ = S.render(ns, row0=row, rows=1, nthreads=1)
         assert np.array_equal(bits(got[row]), bits(ref[0])), "row %d" % row
+
+
+@pytest.mark.gpu
+def test_calls_captured_in_a_hip_graph(rt, cuda):
+    """after one warm-up call (workspace allocations) the launches of rt_render / rt_render_progressive can be
+    captured into a hipGraph.  Replaying the graph gives the bits of the direct calls: a progressive loop (fb += col, the RNG
+    state continuing) and whole renders (counter reset, pilot pass with and without long-chain classification, tile order,
+    render kernel), each replayed three times — a stale work queue would show as an untouched RNG state."""
+    torch = cuda
+    nx, ny, n, spl, passes = 400, 225, 500, 30, 8
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, spl)
+
+    def progressive(direct):
+        st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
+        rt.render_init(nx, ny, st)
+        rt.render_progressive(fb, nx, ny, 1, W, st, O)                # fb = col
+        rt.render_progressive(fb, nx, ny, 2, W, st, O)                # fb += col
+        torch.cuda.synchronize()
+        if direct:
+            for k in range(3, passes + 1):
+                rt.render_progressive(fb, nx, ny, k, W, st, O)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                rt.render_progressive(fb, nx, ny, 3, W, st, O)        # captured, not executed
+            for k in range(3, passes + 1):
+                g.replay()
+        torch.cuda.synchronize()
+        return fb.clone(), st.clone()
+
+    a, sa = progressive(True)
+    b, sb = progressive(False)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(sa, sb)
+
+    for ns in (8, 16):
+        fb0, st0 = gpu_render(rt, torch, W, O, nx, ny, ns)             # also the warm-up of this frame size
+        st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            rt.render_init(nx, ny, st)
+            rt.render(fb, nx, ny, ns, W, st, O)
+        for _ in range(3):                                             # every replay starts from render_init again
+            fb.zero_()
+            g.replay(); torch.cuda.synchronize()
+            assert torch.equal(fb.view(torch.int32), fb0.view(torch.int32)) and torch.equal(st, st0)
