@@ -77,6 +77,7 @@ def test_trace_hit_records(rt, cuda, n, spl, tree):
     (22, 64, 36, 4, False, 30), (22, 64, 36, 4, True, 30),
     (500, 64, 36, 4, False, 30), (500, 61, 35, 3, True, 30),      # ragged: not a multiple of the 8x8 tile
     (10000, 48, 32, 2, True, 32), (10000, 48, 32, 2, False, 32),
+    (5, 40, 24, 16, True, 30), (5, 40, 24, 16, False, 30),       # the smallest world create_world accepts; 16 spp: long-chain pass on
 ])
 def test_render_small_frames(rt, cuda, n, nx, ny, ns, tree, spl):
     """render(): float framebuffer and written-back RNG state bit-identical to the oracle."""
