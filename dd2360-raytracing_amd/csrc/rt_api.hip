@@ -323,13 +323,17 @@ int64_t rt_part_pixels(int max_x, int max_y, rt_partition part) {
 }
 
 int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partition part, void* stream) {
-    if (max_x <= 0 || max_y <= 0 || !d_rand_state || !valid_partition(part)) return RT_EINVAL;
+    if (max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
+    if (rt_part_pixels(max_x, max_y, part) == 0) return 0;            // a part without tiles (more parts than tiles): nothing to do
+    if (!d_rand_state) return RT_EINVAL;
     return (int)launch_render_init(d_rand_state, max_x, max_y, part.part, part.nparts, (hipStream_t)stream);
 }
 
 static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
-    if (!fb || !world || !d_rand_state || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
+    if (!world || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
+    if (rt_part_pixels(max_x, max_y, part) == 0) return 0;            // a part without tiles (more parts than tiles): nothing to do
+    if (!fb || !d_rand_state) return RT_EINVAL;
     int rc = rt_world_upload(const_cast<rt_world*>(world));
     if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
     if (rc) return rc;

@@ -70,6 +70,17 @@ def test_world_camera_octree_match_oracle(rt, precision, n, spl):
     assert info["flat_nodes"] == info["node_count"] and info["flat_entries"] == live_entries
 
 
+def test_part_without_tiles_is_a_no_op(rt):
+    # 8x8 frame = one tile dealt to part 0 of 3: parts 1 and 2 own nothing, their calls succeed without touching the device
+    L = rt.lib()
+    W = rt.World(22, 8, 8)
+    assert rt.part_pixels(8, 8, rt.Partition(1, 3)) == 0
+    assert L.rt_render_init(8, 8, None, rt.Partition(1, 3), None) == 0
+    assert L.rt_render(None, 8, 8, 4, W.h, None, None, rt.Partition(2, 3), None) == 0
+    assert L.rt_render_progressive(None, 8, 8, 1, W.h, None, None, rt.Partition(2, 3), None) == 0
+    assert L.rt_render(None, 8, 8, 4, W.h, None, None, rt.Partition(0, 3), None) == -1        # part 0 has pixels: buffers are required
+
+
 def test_camera_init_matches_create_world(rt):
     W = rt.World(22, 1200, 800)
     cam = rt.camera_init((13, 2, 3), (0, 0, 0), (0, 1, 0), 30.0, np.float32(1200) / np.float32(800), np.float32(0.1), 10.0)
