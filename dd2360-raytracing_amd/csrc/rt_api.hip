@@ -60,7 +60,7 @@ struct rt_octree {
     int traversal = RT_TRAVERSAL_FAST;
     DevTree dev{};
     void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
-    void* d_acc[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [7] = node1
+    void* d_acc[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // rt_octree_upload: large_hot, large_brick, cs, hot, brick, memb_start, memb_cell, -, cellnode, bits_index, cellbits
 };
 
 template <class T> static int upload(const std::vector<T>& v, void** d) {
