@@ -521,3 +521,24 @@ def test_calls_captured_in_a_hip_graph(rt, cuda):
             fb.zero_()
             g.replay(); torch.cuda.synchronize()
             assert torch.equal(fb.view(torch.int32), fb0.view(torch.int32)) and torch.equal(st, st0)
+
+
+@pytest.mark.gpu
+def test_c5_geometry_rows_against_the_oracle(rt, cuda):
+    """BASELINE config 5's scene and frame (3840x2160, N = 100000, SPL 320 — the dense grid, rendered by the plain kernel variant)
+    at 8 spp: sampled rows equal the oracle bit for bit, fast traversal equals the reference scan over the whole frame."""
+    torch = cuda
+    nx, ny, ns, n, spl = 3840, 2160, 8, 100000, 320
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, spl)
+    assert O.info()["dropped_full"] == 0
+    fb, st = gpu_render(rt, torch, W, O, nx, ny, ns)
+    O.set_traversal(rt.TRAVERSAL_REFERENCE)
+    fb2, st2 = gpu_render(rt, torch, W, O, nx, ny, ns)
+    O.set_traversal(rt.TRAVERSAL_FAST)
+    assert torch.equal(fb.view(torch.int32), fb2.view(torch.int32)) and torch.equal(st, st2)
+    got = fb.cpu().numpy().reshape(ny, nx, 3)
+    S = OracleScene(n, nx, ny, use_octree=True, spl=spl)
+    for row in (40, 700, 1100, 2100):
+        ref, _ = S.render(ns, row0=row, rows=1, nthreads=8)
+        assert np.array_equal(bits(got[row]), bits(ref[0])), "row %d differs" % row
