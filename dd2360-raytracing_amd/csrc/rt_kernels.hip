@@ -34,9 +34,14 @@ namespace rt {
 #ifndef RT_RENDER_WAVES
 #define RT_RENDER_WAVES 3
 #endif
-// grid entries tested per walk step (loads in flight together)
-#ifndef RT_BATCH
-#define RT_BATCH 4
+// grid entries tested per walk step (loads in flight together): on sparse grids (C3: 3.6 entries per cell; the kernel variant
+// with grouped cooperative walks) / on dense grids (C5: 37 per cell; the plain variant).  Measured: C3 4: 22.9 ms, 6: 22.7, 8: 23.5;
+// C5 4: 144.8 ms, 6: 133.5, 8: 129.6.
+#ifndef RT_BATCH_SPARSE
+#define RT_BATCH_SPARSE 6
+#endif
+#ifndef RT_BATCH_DENSE
+#define RT_BATCH_DENSE 8
 #endif
 // phase B starts when holders * RT_VOTE_NUM >= searchers (or nobody searches)
 #ifndef RT_VOTE_NUM
@@ -686,6 +691,7 @@ RT_DEV void walk_coop_g(const DevTree& T, const float4* s_nodes, const RayF& r, 
 // `tie` is set when the result must be recomputed by the reference scan (exact tie between two tree spheres).
 // `budget` > 0: return after that many phase-A iterations even if some lanes have not finished; their position is left
 // in W (W.walking stays true) and the walk is resumed by the next call.
+template <int RT_BATCH>
 RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int& e, int& e_end, int budget, float& best_t, int& best, bool& tie STAT_ARG) {
     const DevAccel& A = T.acc;
     const int32_t* __restrict__ cs = A.cs;
@@ -921,7 +927,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             while (__popcll(todo) > 1) { const int L = pop(); walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS); }
             if (todo != 0ull) walk_coop(T, s_nodes, r, a, ts.W, lane_ == __ffsll((long long)todo) - 1, closest, best, ts.tie STAT_PASS);
         }
-        else if (walker) walk_lanes(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
+        else if (walker) walk_lanes<(COOPG >= 4 ? RT_BATCH_SPARSE : RT_BATCH_DENSE)>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
         if (walker) {
             ts.pending = ts.W.walking;
             if (!ts.pending && ts.tie) { closest = ts.g_t; best = ts.g_id; slow = true; STAT(st, ST_TIE, 1); }
