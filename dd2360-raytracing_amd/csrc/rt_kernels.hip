@@ -43,9 +43,12 @@ namespace rt {
 #ifndef RT_BATCH_DENSE
 #define RT_BATCH_DENSE 8
 #endif
-// phase B starts when holders * RT_VOTE_NUM >= searchers (or nobody searches)
-#ifndef RT_VOTE_NUM
-#define RT_VOTE_NUM 3
+// phase B starts when holders * VOTE >= searchers (or nobody searches); sparse / dense grids (C5: 2 -> 126 ms, 3 -> 122, 5 -> 120)
+#ifndef RT_VOTE_SPARSE
+#define RT_VOTE_SPARSE 3
+#endif
+#ifndef RT_VOTE_DENSE
+#define RT_VOTE_DENSE 5
 #endif
 // a pixel averaging at least this many bounces per sample is a long chain (the scene average is ~2.7)
 #ifndef RT_LONG_RATE
@@ -66,8 +69,12 @@ namespace rt {
 // A per-lane walk returns once only 1/RT_QUORUM_DEN of the lanes that entered it are still walking (in waves that entered
 // with >= RT_QUORUM_MIN walkers): the stragglers keep their position (TreeState) and resume on the next call, together
 // with the new rays of the lanes that went on to shade.  Measured on C3: off 32.3 ms, 2: 31.8, 4: 31.2, 8: 30.6, 16: 31.1.
-#ifndef RT_QUORUM_DEN
-#define RT_QUORUM_DEN 8
+// On dense grids walks are long and uneven, leaving earlier pays: C5 off 134.8 ms, 1/16: 126.1, 1/8: 122.1, 1/4: 118.5, 1/2: 114.3.
+#ifndef RT_QUORUM_SPARSE
+#define RT_QUORUM_SPARSE 8
+#endif
+#ifndef RT_QUORUM_DENSE
+#define RT_QUORUM_DENSE 2
 #endif
 #ifndef RT_QUORUM_MIN
 #define RT_QUORUM_MIN 16
@@ -691,7 +698,7 @@ RT_DEV void walk_coop_g(const DevTree& T, const float4* s_nodes, const RayF& r, 
 // `tie` is set when the result must be recomputed by the reference scan (exact tie between two tree spheres).
 // `budget` > 0: return after that many phase-A iterations even if some lanes have not finished; their position is left
 // in W (W.walking stays true) and the walk is resumed by the next call.
-template <int RT_BATCH>
+template <int RT_BATCH, int RT_QUORUM_DEN, int RT_VOTE_NUM>
 RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int& e, int& e_end, int budget, float& best_t, int& best, bool& tie STAT_ARG) {
     const DevAccel& A = T.acc;
     const int32_t* __restrict__ cs = A.cs;
@@ -927,7 +934,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             while (__popcll(todo) > 1) { const int L = pop(); walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS); }
             if (todo != 0ull) walk_coop(T, s_nodes, r, a, ts.W, lane_ == __ffsll((long long)todo) - 1, closest, best, ts.tie STAT_PASS);
         }
-        else if (walker) walk_lanes<(COOPG >= 4 ? RT_BATCH_SPARSE : RT_BATCH_DENSE)>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
+        else if (walker) walk_lanes<(COOPG >= 4 ? RT_BATCH_SPARSE : RT_BATCH_DENSE), (COOPG >= 4 ? RT_QUORUM_SPARSE : RT_QUORUM_DENSE), (COOPG >= 4 ? RT_VOTE_SPARSE : RT_VOTE_DENSE)>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
         if (walker) {
             ts.pending = ts.W.walking;
             if (!ts.pending && ts.tie) { closest = ts.g_t; best = ts.g_id; slow = true; STAT(st, ST_TIE, 1); }
