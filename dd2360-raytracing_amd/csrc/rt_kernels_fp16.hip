@@ -135,7 +135,16 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             }
             const bool has = e < e_end;
             if (__ballot(has) == 0ull) break;
-            if (has) { sphere_test(r, a, T.ent_hot[e], e, closest, e_best); ++e; }
+            if (has) {
+                // up to four entries of the range per pass, their loads in flight together; tested strictly in order
+                const int m = e_end - e;
+                const float4 s0 = T.ent_hot[e], s1 = T.ent_hot[m > 1 ? e + 1 : e], s2 = T.ent_hot[m > 2 ? e + 2 : e], s3 = T.ent_hot[m > 3 ? e + 3 : e];
+                sphere_test(r, a, s0, e, closest, e_best);
+                if (m > 1) sphere_test(r, a, s1, e + 1, closest, e_best);
+                if (m > 2) sphere_test(r, a, s2, e + 2, closest, e_best);
+                if (m > 3) sphere_test(r, a, s3, e + 3, closest, e_best);
+                e += m > 4 ? 4 : m;
+            }
         }
         if (__ballot(node < n_nodes) == 0ull) break;
     }
