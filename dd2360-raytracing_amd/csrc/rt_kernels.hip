@@ -95,6 +95,10 @@ namespace rt {
 #define RT_LONG_PER_WAVE 4
 #endif
 // list path: rays are scanned cooperatively (lanes = spheres) while live_rays * RT_LIST_COOP_COST <= list size
+// list path: spheres per pass of the linear scan
+#ifndef RT_LIST_BATCH
+#define RT_LIST_BATCH 8
+#endif
 #ifndef RT_LIST_COOP_COST
 #define RT_LIST_COOP_COST 16
 #endif
@@ -290,7 +294,15 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
         }
         return;
     }
-    for (int k = 0; k < n; ++k) {
+    int k = 0;
+    for (; k + RT_LIST_BATCH <= n; k += RT_LIST_BATCH) {         // several spheres per pass: their (scalar) loads in flight together
+        float4 sv[RT_LIST_BATCH];
+#pragma unroll
+        for (int q = 0; q < RT_LIST_BATCH; ++q) sv[q] = hot[k + q];
+#pragma unroll
+        for (int q = 0; q < RT_LIST_BATCH; ++q) sphere_test(r, a, sv[q].x, sv[q].y, sv[q].z, sv[q].w, k + q, closest, best);
+    }
+    for (; k < n; ++k) {
         const float4 s = hot[k];
         sphere_test(r, a, s.x, s.y, s.z, s.w, k, closest, best);
     }
