@@ -92,7 +92,15 @@ RT_DEV bool ray_box(const Ray& r, const float4 n0, const float4 n1) {
 
 RT_DEV void closest_list(const DevScene& S, const Ray& r, R a, R& closest, int& best) {
     const float4* __restrict__ hot = S.list_hot;
-    for (int k = 0; k < S.n_list; ++k) sphere_test(r, a, hot[k], k, closest, best);
+    int k = 0;
+    for (; k + 8 <= S.n_list; k += 8) {                      // eight spheres per pass: their (scalar) loads in flight together
+        float4 sv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv[q] = hot[k + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sphere_test(r, a, sv[q], k + q, closest, best);
+    }
+    for (; k < S.n_list; ++k) sphere_test(r, a, hot[k], k, closest, best);
     if (best >= 0) best = S.list_id[best];
 }
 
