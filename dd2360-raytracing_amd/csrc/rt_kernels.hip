@@ -281,11 +281,17 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
             q.d.x = bcast(r.d.x, L); q.d.y = bcast(r.d.y, L); q.d.z = bcast(r.d.z, L);
             const float qa = bcast(a, L);
             float my_t = FLT_MAX; int my_k = 0x7fffffff;
-            for (int base = 0; base < n; base += 64) {
-                const int k = base + lane;
-                if (k < n) {
-                    const float cand = sphere_candidate(q, qa, hot[k]);
-                    if (cand < my_t) { my_t = cand; my_k = k; }
+            for (int base = 0; base < n; base += 256) {          // four spheres per lane and pass, their loads in flight together
+                float4 sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int k = base + u * 64 + lane; sv[u] = hot[k < n ? k : n - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = base + u * 64 + lane;
+                    if (k < n) {
+                        const float cand = sphere_candidate(q, qa, sv[u]);
+                        if (cand < my_t) { my_t = cand; my_k = k; }
+                    }
                 }
             }
             const float mn = group_min<64>(my_t);
