@@ -339,9 +339,14 @@ RT_DEV void tree_scan(const float4* s_nodes, const RayF& r, float a, bool live, 
             }
         }
         if (e >= e_end) break;          // no node left for this lane (it waits at the loop exit for the rest of the wave)
-        for (; e < e_end; ++e) {
-            const float4 s = T.ent_hot[e];
-            sphere_test(r, a, s.x, s.y, s.z, s.w, e, closest, e_best);
+        while (e < e_end) {                             // four entries per pass, their loads in flight together; tested in order
+            const int m = e_end - e;
+            const float4 s0 = T.ent_hot[e], s1 = T.ent_hot[m > 1 ? e + 1 : e], s2 = T.ent_hot[m > 2 ? e + 2 : e], s3 = T.ent_hot[m > 3 ? e + 3 : e];
+            sphere_test(r, a, s0.x, s0.y, s0.z, s0.w, e, closest, e_best);
+            if (m > 1) sphere_test(r, a, s1.x, s1.y, s1.z, s1.w, e + 1, closest, e_best);
+            if (m > 2) sphere_test(r, a, s2.x, s2.y, s2.z, s2.w, e + 2, closest, e_best);
+            if (m > 3) sphere_test(r, a, s3.x, s3.y, s3.z, s3.w, e + 3, closest, e_best);
+            e += m > 4 ? 4 : m;
         }
     }
     if (e_best >= 0) best = T.ent_id[e_best];
