@@ -240,7 +240,17 @@ int rt_octree_upload(rt_octree* O) {
     if (!O) return RT_EINVAL;
     if (O->uploaded) return 0;
     int rc;
-    if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_hot, &O->d_ent_hot)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
+    if (O->precision == RT_PRECISION_FP16) {
+        // binary16 trees: the bucket entries as four halves (cx, cy, cz, r^2) in 8 bytes — the values are binary16 numbers
+        // already, this saves the fp16 scan four conversions and half the bytes per sphere test (rt_kernels_fp16.hip)
+        std::vector<uint2> packed(O->h_ent_hot.size());
+        for (size_t k = 0; k < packed.size(); ++k) {
+            const float4 v = O->h_ent_hot[k];
+            packed[k] = make_uint2((uint32_t)half_t(v.x).bits | ((uint32_t)half_t(v.y).bits << 16), (uint32_t)half_t(v.z).bits | ((uint32_t)half_t(v.w).bits << 16));
+        }
+        if ((rc = upload(packed, &O->d_ent_hot))) return rc;
+    } else if ((rc = upload(O->h_ent_hot, &O->d_ent_hot))) return rc;
+    if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
     O->dev.nodes4 = (const float4*)O->d_nodes; O->dev.ent_hot = (const float4*)O->d_ent_hot; O->dev.ent_id = (const int32_t*)O->d_ent_id;
     AccelHost& A = O->accel;
     if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_brick, &O->d_acc[1])) || (rc = upload(A.cs, &O->d_acc[2])) ||

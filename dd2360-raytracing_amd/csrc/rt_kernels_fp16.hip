@@ -71,6 +71,25 @@ RT_DEV void sphere_test(const Ray& r, R a, const float4 s, int id, R& closest, i
         }
     }
 }
+// the same for a bucket entry of a binary16 tree: four halves (cx, cy, cz, r^2) in 8 bytes (rt_api.hip, rt_octree_upload)
+RT_DEV R hbits(uint32_t b) { R r; r.bits = (uint16_t)b; return r; }
+RT_DEV void sphere_test(const Ray& r, R a, const uint2 pk, int id, R& closest, int& best) {
+    const V c = {hbits(pk.x & 0xffffu), hbits(pk.x >> 16), hbits(pk.y & 0xffffu)};
+    const V oc = vsub(r.o, c);
+    const R b = vdot(oc, r.d);
+    const R cc = vdot(oc, oc) - hbits(pk.y >> 16);                   // s.w = radius*radius, rounded to binary16 on the host
+    const R disc = b * b - a * cc;
+    if (disc > ri(0)) {
+        const R tmin = rf(0.001f);
+        const float nb = -fl(b);
+        R t = rf((nb - fl(rsqrt_(disc))) / fl(a));         // float arithmetic on converted operands, one rounding
+        if (t < closest && t > tmin) { closest = t; best = id; }
+        else {
+            t = rf((nb + sqrtf(fl(disc))) / fl(a));        // far root: float sqrt of float(disc), not rounded (sphere.h:36)
+            if (t < closest && t > tmin) { closest = t; best = id; }
+        }
+    }
+}
 
 // intersect_ray_aabb (acceleration_structure.h:226-244): real_t arithmetic, float results
 RT_DEV bool ray_box(const Ray& r, const float4 n0, const float4 n1) {
@@ -146,7 +165,8 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             if (has) {
                 // up to four entries of the range per pass, their loads in flight together; tested strictly in order
                 const int m = e_end - e;
-                const float4 s0 = T.ent_hot[e], s1 = T.ent_hot[m > 1 ? e + 1 : e], s2 = T.ent_hot[m > 2 ? e + 2 : e], s3 = T.ent_hot[m > 3 ? e + 3 : e];
+                const uint2* __restrict__ ent = (const uint2*)T.ent_hot;
+                const uint2 s0 = ent[e], s1 = ent[m > 1 ? e + 1 : e], s2 = ent[m > 2 ? e + 2 : e], s3 = ent[m > 3 ? e + 3 : e];
                 sphere_test(r, a, s0, e, closest, e_best);
                 if (m > 1) sphere_test(r, a, s1, e + 1, closest, e_best);
                 if (m > 2) sphere_test(r, a, s2, e + 2, closest, e_best);
