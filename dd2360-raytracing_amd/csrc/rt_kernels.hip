@@ -59,6 +59,12 @@ namespace rt {
 #define RT_THIN_CAP_DEN 4
 #endif
 // waves with at most this many rays on the fast path walk the grid cooperatively (lanes = spheres; 1, 2 or 4 rays at a time)
+// a pixel averaging at least this many bounces per sample (below RT_LONG_RATE) is a medium chain: its wave keeps refilling
+// but issues at priority 1 — the frame is as long as these chains are slow; 0 = off.  C3: off 22.88 ms,
+// 10: 22.62, 12: 22.51, 15: 22.53; priority 2 instead of 1: the same
+#ifndef RT_MED_RATE
+#define RT_MED_RATE 12
+#endif
 #ifndef RT_COOP_MAX
 #define RT_COOP_MAX 8
 #endif
@@ -1141,6 +1147,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     int i = 0, j = 0; long long idx = 0;
     unsigned int iters = 0;             // bounces spent on the current pixel
     bool is_long = false;               // the current pixel has been classified long
+    bool is_med = false;                // ... medium: its wave issues at priority 1
     bool retired = false;               // the queue was empty when this lane last asked
     bool thin = false;                  // wave-uniform: this wave holds a long pixel and does not refill
     bool thin_counted = false;          // wave-uniform: this wave is included in the global thin-wave count
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 #ifdef RT_ONLY_LANE
         if (lane != RT_ONLY_LANE) return;                  // probe build: one pixel chain alone in its wave
 #endif
-        iters = 0; is_long = false;
+        iters = 0; is_long = false; is_med = false;
         while (slot < n_slots) {
             // Slots are interleaved over blocks of 64 tiles (in hand-out order): consecutive slots are the same pixel
             // position of 64 different tiles, so the pixels of one tile (long chains cluster) never travel together.
@@ -1275,6 +1282,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             if (thin_counted && lane == 0) atomicSub(A.queue + 1, 1u);
             thin_counted = false;
         }
+        if (RT_MED_RATE > 0 && !thin) { if (__ballot(live && is_med) != 0ull) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if (!thin) {
             // idle lanes (their pixel ended while the wave was thin) go back to the queue
             if (!live && !retired) { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
@@ -1328,6 +1336,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 #endif
                         is_long = true;
                     }
+                    else if (RT_MED_RATE > 0 && (sample & 7) == 0 && iters >= (unsigned int)(RT_MED_RATE * sample)) is_med = true;
                 } else {
                     WPASS(WP_ENDPIX);
                     end_pixel();
@@ -1335,7 +1344,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                     pix_iters = 0;
 #endif
                     STAT(st, ST_SWITCHES, 1);
-                    live = false; is_long = false;
+                    live = false; is_long = false; is_med = false;
                     if (lane < RT_LONG_PER_WAVE && begin_long_pixel()) { /* next long chain */ }
                     else if (!thin) { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
                 }
