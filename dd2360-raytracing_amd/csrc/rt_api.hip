@@ -63,11 +63,11 @@ struct rt_octree {
     void* d_acc[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // rt_octree_upload: large_hot, large_brick, cs, hot, brick, memb_start, memb_cell, -, cellnode, bits_index, cellbits
 };
 
-template <class T> static int upload(const std::vector<T>& v, void** d) {
+template <class V> static int upload(const V& v, void** d) {
     *d = nullptr;
-    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(typename V::value_type);
     RT_TRY(hipMalloc(d, bytes));
-    if (!v.empty()) RT_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) RT_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(typename V::value_type), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -279,7 +279,7 @@ int rt_octree_accel_info(const rt_octree* O, int* grid_dim, float* cell_size, in
     if (!O) return RT_EINVAL;
     if (grid_dim) *grid_dim = O->accel.p.G;
     if (cell_size) *cell_size = O->accel.p.h;
-    if (grid_entries) *grid_entries = (int)((O->accel.id.size() - 16) / 2);
+    if (grid_entries) *grid_entries = (int)O->accel.n_entries;
     if (large_spheres) *large_spheres = O->accel.p.n_large;
     return 0;
 }

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Start-up cost outside the timed region: create_world, buildOctree + candidate grid, upload.
+usage: python tools/setup_time.py [num_spheres spheres_per_leaf]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dd2360-raytracing_amd"))
+import rt_amd as rt
+
+def main():
+    cases = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(10000, 32), (100000, 320)]
+    rt.lib()
+    gpu = False
+    try:
+        import torch
+        gpu = torch.cuda.is_available()
+        if gpu: torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+    except Exception:
+        pass
+    for n, spl in cases:
+        for rep in range(3):
+            t0 = time.perf_counter(); w = rt.World(n, 3840, 2160)
+            t1 = time.perf_counter(); o = rt.Octree(w, spl)
+            t2 = time.perf_counter()
+            if gpu: w.upload(); o.upload(); torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            print("N=%d spl=%d: create_world %.1f ms, build_octree + grid %.1f ms, upload %s" %
+                  (n, spl, (t1 - t0) * 1e3, (t2 - t1) * 1e3, "%.1f ms" % ((t3 - t2) * 1e3) if gpu else "skipped (no GPU)"))
+            o.close(); w.close()
+
+if __name__ == "__main__":
+    main()
