@@ -97,6 +97,9 @@ namespace rt {
 #define RT_PILOT_CAP 35     // bounces after which a pilot sample is cut (the pilot pass is as long as its longest chain; 50 = the reference's depth limit)
 #endif
 // long chains started per thin wave
+#ifndef RT_GROUND_SHORT
+#define RT_GROUND_SHORT 1      // skip the exact ground test for rays that leave the ground behind (exact, see closest_tree)
+#endif
 #ifndef RT_LONG_PER_WAVE
 #define RT_LONG_PER_WAVE 4
 #endif
@@ -891,7 +894,16 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         WPASS(WP_GROUND);
         const float4 g = S.list_hot[0];
         int gb = -1;
+#if RT_GROUND_SHORT
+        // origin outside the sphere (c > 0) and heading away from its centre (b > 0): disc <= fl(b*b), so sqrt(disc) <= b and
+        // both roots are <= 0 — the float test cannot pass (no margin involved); saves the exact sqrt and two divisions
+        { const float ocx = r.o.x - g.x, ocy = r.o.y - g.y, ocz = r.o.z - g.z;
+          const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
+          const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
+          if (__ballot(fresh && !(b > 0.0f && c > 0.0f)) != 0ull) sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb); }
+#else
         sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
+#endif
         if (gb == 0) best = 0;
     }
 #ifdef RT_STATS

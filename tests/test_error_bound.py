@@ -149,3 +149,32 @@ def test_brick_margin_puts_t_inside_the_float_slab_interval():
         bare = keep & (u > i0.astype(F)) & (u < (i1 + 1).astype(F))
         near = np.abs(np.where(side == 0, P.astype(np.float64) - X0, X1 - P.astype(np.float64))) < 1e-5
         assert bare.sum() >= inside.sum() and near.sum() == 0          # (the cases above keep >= 0.002 - 1e-4 from the faces)
+
+
+def test_away_from_an_outer_sphere_no_float_root_passes():
+    """closest_tree's ground shortcut (rt_kernels.hip): b > 0 and c > 0 in the reference's float operations ==> fl(sqrt(disc)) <= b,
+    so t1 = (-b - sq)/a and t2 = (-b + sq)/a are both <= 0 < 0.001 — sphere::hit (sphere.h:17-46) cannot accept a root."""
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    # the ground sphere of create_world and small spheres; origins just outside the surface (c tiny), directions from
+    # grazing to radial, |d| over five decades (a*c down to underflow against b*b)
+    big = rng.random(n) < 0.5
+    c3 = np.where(big[:, None], np.array([0.0, -1000.0, -1.0]), rng.uniform(-10, 10, (n, 3)))
+    rad = np.where(big, 1000.0, rng.choice([0.1, 0.2, 1.0], n))
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    o = c3 + u * (rad * (1.0 + 10.0 ** rng.uniform(-8, -1, n)))[:, None]
+    tang = np.cross(u, rng.normal(size=(n, 3))); tang /= np.linalg.norm(tang, axis=1)[:, None]
+    d = (tang + u * (10.0 ** rng.uniform(-8, 0, n))[:, None] * rng.choice([-1.0, 1.0], n)[:, None]) * (10.0 ** rng.uniform(-3, 2, n))[:, None]
+    o32, d32, c32 = o.astype(F), d.astype(F), c3.astype(F)
+    r2 = (rad.astype(F) * rad.astype(F)).astype(F)
+    oc = [(o32[:, k] - c32[:, k]).astype(F) for k in range(3)]
+    dd = [d32[:, k] for k in range(3)]
+    disc, a, b = disc32([o32[:, k] for k in range(3)], dd, [c32[:, k] for k in range(3)], r2)
+    cc = (((oc[0] * oc[0]).astype(F) + (oc[1] * oc[1]).astype(F)).astype(F) + (oc[2] * oc[2]).astype(F)).astype(F) - r2
+    skip = (b > 0) & (cc > 0) & (disc > 0)
+    assert skip.sum() > 200_000
+    sq = np.sqrt(disc[skip]).astype(F)                               # IEEE sqrt, correctly rounded
+    t1 = ((-b[skip] - sq).astype(F) / a[skip]).astype(F)
+    t2 = ((-b[skip] + sq).astype(F) / a[skip]).astype(F)
+    assert (sq <= b[skip]).all()
+    assert not (t1 > F(0.001)).any() and not (t2 > F(0.001)).any()
