@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--list-reference", action="store_true", help="octree-off configs: plain list-order scan instead of the candidate grid")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +105,8 @@ def main():
     # scene: generated on the host exactly as create_world does (seed 1984), resident in HBM before the timed region
     precision = rt.FP16 if cfg.get("fp16") else rt.FP32
     W = rt.World(cfg["spheres"], nx, ny, precision=precision).upload()
+    if args.list_reference:
+        W.set_list_traversal(rt.TRAVERSAL_REFERENCE)
     O = rt.Octree(W, cfg["spl"]).upload() if cfg["octree"] else None
     st = rt.alloc_rand_state(nx, ny, part)
     fb = rt.alloc_fb(nx, ny, part, precision=precision)
@@ -179,7 +182,11 @@ def main():
             ai = O.accel_info()
             kernel_name = "k_render<true,0,%d>" % (4 if ai["grid_entries"] <= 8 * ai["grid_dim"] ** 2 else 1)
         else:
-            kernel_name = "k_render<false,0,1>"
+            ai = W.list_accel_info()
+            if ai["enabled"] and not args.list_reference:             # the list as a one-node tree through the candidate grid
+                kernel_name = "k_render<true,0,%d>" % (4 if ai["grid_entries"] <= 8 * ai["grid_dim"] ** 2 else 1)
+            else:
+                kernel_name = "k_render<false,0,1>"
         flops_launch = cfg["flops_per_sample"] * local_samples
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         traffic = None

@@ -59,7 +59,9 @@ static inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZ
 static inline double accel_Rp(double r2) { return std::sqrt(r2 * (1.0 + 1e-6) + accel_K2()) + 1e-5 + kSlack; }
 
 // nodes/ent_id: the pre-order traversal copy; geom_r2(i) gives (cx,cy,cz,r^2) of world-list index i
-inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const std::vector<int32_t>& ent_id, const std::vector<float4>& ent_hot, int n_world) {
+// list_mode: `nodes` is the single unbounded node that stands for hitable_list::hit (every sphere is eligible everywhere:
+// all bricks are infinite, no cell bookkeeping)
+inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const std::vector<int32_t>& ent_id, const std::vector<float4>& ent_hot, int n_world, bool list_mode = false) {
     // 1. membership: sphere -> level-3 nodes (pre-order index) that hold it
     A.memb_start.assign((size_t)n_world + 1, 0);
     for (size_t k = 0; k < nodes.size(); ++k)
@@ -78,7 +80,7 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     // level-3 cells: the root box (-11,0,-11)-(11,2,11) (acceleration_structure.h:203) halved three times = 8x8x8 cells of
     // 2.75 x 0.25 x 2.75; a level-3 node is recognised by holding entries
     A.cellnode.assign(512, -1);
-    for (size_t k = 0; k < nodes.size(); ++k) {
+    for (size_t k = 0; k < nodes.size() && !list_mode; ++k) {
         if (nodes[k].count <= 0) continue;
         const int ix = (int)std::lround((nodes[k].lo[0] + 11.0) / 2.75), iy = (int)std::lround(nodes[k].lo[1] / 0.25), iz = (int)std::lround((nodes[k].lo[2] + 11.0) / 2.75);
         if (ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) A.cellnode[ix * 64 + iy * 8 + iz] = (int32_t)k;
@@ -120,7 +122,9 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
             const int32_t single = (me - mb == 1) ? A.memb_cell[mb] : -1;
             float idbits, nodebits;
             { const int32_t v = s; std::memcpy(&idbits, &v, 4); std::memcpy(&nodebits, &single, 4); }
-            if (ok) {
+            if (list_mode) {
+                sb_lo[s] = make_float4(-inf, -inf, -inf, idbits); sb_hi[s] = make_float4(inf, inf, inf, nodebits);
+            } else if (ok) {
                 sb_lo[s] = make_float4((float)(lo[0] + kBrickMxz), (float)(lo[1] + kBrickMy), (float)(lo[2] + kBrickMxz), idbits);
                 sb_hi[s] = make_float4((float)(hi[0] + 1 - kBrickMxz), (float)(hi[1] + 1 - kBrickMy), (float)(hi[2] + 1 - kBrickMxz), nodebits);
             } else {

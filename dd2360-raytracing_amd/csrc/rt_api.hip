@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <limits>
 #include "rt_device.h"
 #include "../host/rt_scene.hpp"
 #include "rt_accel.h"
@@ -33,10 +34,14 @@ using namespace rt;
 
 // Handles keep their host staging copy; device buffers are created by rt_world_upload / rt_octree_upload
 // (called implicitly by the first render/trace that uses the handle).
+struct rt_octree;
 struct rt_world {
     int precision = RT_PRECISION_FP32;
     int n = 0;
     bool uploaded = false;
+    // hitable_list::hit through the candidate grid: the list as a one-node "tree" (fp32 only; null = plain scan)
+    rt_octree* list_tree = nullptr;
+    int list_traversal = RT_TRAVERSAL_FAST;
     std::vector<float4> h_hot, h_geom, h_mat;
     std::vector<int32_t> h_ids, h_kind;
     DevScene dev{};
@@ -69,6 +74,32 @@ template <class V> static int upload(const V& v, void** d) {
     RT_TRY(hipMalloc(d, bytes));
     if (!v.empty()) RT_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(typename V::value_type), hipMemcpyHostToDevice));
     return 0;
+}
+
+static bool hittable(const rt_sphere& s);
+static float radius_squared(const rt_sphere& s, int precision);
+// The list as a tree of ONE node without bounds whose entries are the hittable spheres 1..n-1 in list order: hitTree on
+// it (slot 0 first, then the entries in order, strict "<") is hitable_list::hit, so the fp32 octree kernels — and their
+// candidate grid — serve the list path unchanged.  Null when the grid would not pay or cannot be used.
+static rt_octree* build_list_tree(const rt_sphere* list, int n) {
+    rt_octree* O = new rt_octree();
+    O->precision = RT_PRECISION_FP32;
+    DevNode d; memset(&d, 0, sizeof(d));
+    const float inf = std::numeric_limits<float>::infinity();
+    d.lo[0] = d.lo[1] = d.lo[2] = -inf; d.hix = d.hiy = d.hiz = inf;
+    d.skip = 1; d.first = 0; d.ref_index = 0;
+    for (int i = 1; i < n; ++i) {
+        if (!hittable(list[i])) continue;
+        O->h_ent_hot.push_back(make_float4(list[i].center[0], list[i].center[1], list[i].center[2], radius_squared(list[i], RT_PRECISION_FP32)));
+        O->h_ent_id.push_back(i);
+    }
+    d.count = (int32_t)O->h_ent_id.size();
+    O->h_nodes.push_back(d);
+    O->dev.n_nodes = 1; O->dev.n_entries = d.count;
+    if (d.count > 0) build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, n, true);
+    // every ray tests the spheres the grid cannot hold: with many of them the scan is the better list path
+    if (d.count < 64 || !O->accel.p.enabled || O->accel.p.n_large > 64) { delete O; return nullptr; }
+    return O;
 }
 
 static bool valid_partition(rt_partition p) { return p.nparts >= 1 && p.part >= 0 && p.part < p.nparts; }
@@ -162,8 +193,25 @@ int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam
     W->dev.n = num_spheres; W->dev.n_list = (int)hot.size();
     W->dev.ground_valid = hittable(list[0]) ? 1 : 0;
     W->dev.cam = *cam;
+    if (precision == RT_PRECISION_FP32) {
+        try { W->list_tree = build_list_tree(list, num_spheres); }
+        catch (const std::bad_alloc&) { delete W; return RT_ENOMEM; }
+    }
     *out = W;
     return 0;
+}
+
+int rt_world_set_list_traversal(rt_world* W, int mode) {
+    if (!W || (mode != RT_TRAVERSAL_REFERENCE && mode != RT_TRAVERSAL_FAST)) return RT_EINVAL;
+    W->list_traversal = mode;
+    return 0;
+}
+
+int rt_world_list_accel_info(const rt_world* W, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres) {
+    if (!W) return RT_EINVAL;
+    if (enabled) *enabled = W->list_tree != nullptr;
+    if (!W->list_tree) { if (grid_dim) *grid_dim = 0; if (cell_size) *cell_size = 0.f; if (grid_entries) *grid_entries = 0; if (large_spheres) *large_spheres = 0; return 0; }
+    return rt_octree_accel_info(W->list_tree, grid_dim, cell_size, grid_entries, large_spheres);
 }
 
 int rt_world_upload(rt_world* W) {
@@ -183,6 +231,7 @@ int rt_world_upload(rt_world* W) {
 int rt_free_world(rt_world* W) {
     if (!W) return 0;
     int rc = 0;
+    if (W->list_tree) { rc = rt_free_octree(W->list_tree); W->list_tree = nullptr; }
     void* bufs[10] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue, W->d_cost, W->d_order, W->d_flags, W->d_long};
     for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
     if (W->ev_ready) for (int k = 0; k < 64; ++k) { (void)hipEventDestroy(W->ev0[k]); (void)hipEventDestroy(W->ev1[k]); }
@@ -339,11 +388,17 @@ int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partiti
     return (int)launch_render_init(d_rand_state, max_x, max_y, part.part, part.nparts, (hipStream_t)stream);
 }
 
+// no octree passed: the world's one-node list tree, if it has one and the fast list traversal is selected
+static const rt_octree* list_tree_of(const rt_world* world) {
+    return (world->list_tree && world->list_traversal == RT_TRAVERSAL_FAST) ? world->list_tree : nullptr;
+}
+
 static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
     if (!world || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
     if (rt_part_pixels(max_x, max_y, part) == 0) return 0;            // a part without tiles (more parts than tiles): nothing to do
     if (!fb || !d_rand_state) return RT_EINVAL;
+    if (!d_octree) d_octree = list_tree_of(world);                    // hitable_list::hit through the candidate grid
     int rc = rt_world_upload(const_cast<rt_world*>(world));
     if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
     if (rc) return rc;
@@ -433,6 +488,7 @@ int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int n
 int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float* d_rays, int64_t n, rt_hit_record* d_out, void* stream) {
     if (!world || !d_rays || !d_out || n < 0) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
+    if (!d_octree) d_octree = list_tree_of(world);
     int rc = rt_world_upload(const_cast<rt_world*>(world));
     if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
     if (rc) return rc;

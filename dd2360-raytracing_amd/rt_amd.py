@@ -57,6 +57,8 @@ SYMBOLS = {
     "rt_octree_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rt_octree_flat_info": (_i, [_vp, _vp, _vp]),
     "rt_octree_set_traversal": (_i, [_vp, _i]),
+    "rt_world_set_list_traversal": (_i, [_vp, _i]),
+    "rt_world_list_accel_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rt_octree_accel_info": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rt_octree_nodes": (_i, [_vp, _vp]),
     "rt_octree_leaves": (_i, [_vp, _vp, _vp]),
@@ -161,6 +163,16 @@ class World:
     def upload(self):
         check(lib().rt_world_upload(self.h), "rt_world_upload")
         return self
+
+    def set_list_traversal(self, mode):
+        """TRAVERSAL_REFERENCE (every sphere in list order) or TRAVERSAL_FAST (default: the candidate grid) for renders without an octree"""
+        check(lib().rt_world_set_list_traversal(self.h, mode), "rt_world_set_list_traversal")
+        return self
+
+    def list_accel_info(self):
+        e, g, h, n, l = C.c_int(0), C.c_int(0), C.c_float(0), C.c_int(0), C.c_int(0)
+        check(lib().rt_world_list_accel_info(self.h, C.byref(e), C.byref(g), C.byref(h), C.byref(n), C.byref(l)), "rt_world_list_accel_info")
+        return {"enabled": bool(e.value), "grid_dim": g.value, "cell_size": h.value, "grid_entries": n.value, "large_spheres": l.value}
 
     def render_times(self):
         """device times (ms) of the render kernel of the calls since the last query (HIP events on the launch stream)"""

@@ -113,12 +113,22 @@ int rt_create_world(rt_sphere* list, int num_spheres, float sphere_radius, rt_ca
 int rt_camera_init(rt_camera* cam, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,
                    float aspect, float aperture, float focus_dist, int precision);
 
+#define RT_TRAVERSAL_REFERENCE 0
+#define RT_TRAVERSAL_FAST 1
+
 /* Describes list + camera for the device: replaces the cudaMalloc'ed d_list/d_world/d_camera (main.cu:393-401).
  * Host-only; the device copy is made by rt_world_upload. */
 int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam, int precision, rt_world** out);
 /* Creates the device buffers now (otherwise the first render/trace using the handle does it; call this before
  * capturing launches into a hipGraph, since it allocates). */
 int rt_world_upload(rt_world* world);
+/* How hitable_list::hit (hitable_list.h:16-31, the path taken when no octree is passed) runs on the device.  Both give the
+ * reference's hit records bit for bit (fp32): REFERENCE tests every sphere in list order; FAST (default) tests only the
+ * spheres the conservative (x,z) grid of the octree path says the ray can touch (the list seen as one unbounded node:
+ * lowest index wins among equal t, exactly like the sequential scan) and falls back to the scan for rays it cannot prove.
+ * FP16 worlds, and lists with more than 64 spheres outside the grid's range, always use REFERENCE. */
+int rt_world_set_list_traversal(rt_world* world, int mode);   /* RT_TRAVERSAL_REFERENCE | RT_TRAVERSAL_FAST */
+int rt_world_list_accel_info(const rt_world* world, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres);
 /* free_world<<<1,1>>> + cudaFree — main.cu:206-219, :464-466. */
 int rt_free_world(rt_world* world);
 
@@ -132,8 +142,6 @@ int rt_octree_flat_info(const rt_octree* octree, int* n_nodes, int* n_entries); 
  * REFERENCE scans every bucket of every visited level-3 node like traverseTree (acceleration_structure.h:276-304);
  * FAST (default) tests only the spheres a conservative (x,z) grid says the ray can touch and falls back to the scan
  * for rays it cannot prove.  FP16 trees always use REFERENCE. */
-#define RT_TRAVERSAL_REFERENCE 0
-#define RT_TRAVERSAL_FAST 1
 int rt_octree_set_traversal(rt_octree* octree, int mode);
 int rt_octree_accel_info(const rt_octree* octree, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres);
 /* reference-layout view of the built tree (for parity checks): counts[0..leafCount), indices[leafCount*spl] */

@@ -49,17 +49,20 @@ def random_rays(n, seed):
 
 
 @pytest.mark.parametrize("n,spl", [(22, 30), (500, 30), (10000, 32)])
-@pytest.mark.parametrize("tree", ["list", "tree_reference", "tree_fast"])
+@pytest.mark.parametrize("tree", ["list", "list_reference", "tree_reference", "tree_fast"])
 def test_trace_hit_records(rt, cuda, n, spl, tree):
-    """hitTree (both traversal modes) / hitable_list::hit: per-ray hit records bit-identical to the oracle."""
+    """hitTree / hitable_list::hit (both traversal modes each): per-ray hit records bit-identical to the oracle."""
     torch = cuda
     nrays = 200_000 if n <= 500 else 60_000
     rays = random_rays(nrays, 1234 + n)
     W = rt.World(n, 1200, 800)
-    O = rt.Octree(W, spl) if tree != "list" else None
+    O = rt.Octree(W, spl) if not tree.startswith("list") else None
     if O is not None:
         O.set_traversal(rt.TRAVERSAL_FAST if tree == "tree_fast" else rt.TRAVERSAL_REFERENCE)
-    tree = tree != "list"
+    else:
+        assert W.list_accel_info()["enabled"] == (n >= 500)        # the candidate grid serves lists from 64 spheres on
+        W.set_list_traversal(rt.TRAVERSAL_REFERENCE if tree == "list_reference" else rt.TRAVERSAL_FAST)
+    tree = not tree.startswith("list")
     d_rays = torch.from_numpy(rays).cuda()
     d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
     rt.trace_rays(W, O, d_rays, nrays, d_out)
@@ -119,6 +122,19 @@ def test_fast_traversal_equals_reference_scan_many_rays(rt, cuda):
         assert bad.size == 0, "n=%d: %d rays differ, first %s" % (n, bad.size, rays[bad[:3]])
         hits = (outs[0][:, 7].view(np.int32) >= 0).mean()
         assert hits > 0.2
+        if n > 10000:
+            continue
+        # ... and hitable_list::hit: every sphere in list order against the candidate grid
+        assert W.list_accel_info()["enabled"]
+        outs = []
+        for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_FAST):
+            W.set_list_traversal(mode)
+            d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+            rt.trace_rays(W, None, d_rays, nrays, d_out)
+            torch.cuda.synchronize()
+            outs.append(d_out.cpu().numpy().view(np.uint32).reshape(nrays, 8))
+        bad = np.nonzero((outs[0] != outs[1]).any(axis=1))[0]
+        assert bad.size == 0, "list, n=%d: %d rays differ, first %s" % (n, bad.size, rays[bad[:3]])
 
 
 def test_c1_ppm_md5(rt, cuda):
@@ -236,6 +252,13 @@ def test_list_equals_octree_c2_scene(rt, cuda):
     a, _ = gpu_render(rt, torch, W, None, nx, ny, ns)
     b, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # the list path again, every sphere in list order instead of the candidate grid: the same frame and RNG states
+    W.set_list_traversal(rt.TRAVERSAL_REFERENCE)
+    c, st_c = gpu_render(rt, torch, W, None, nx, ny, ns)
+    W.set_list_traversal(rt.TRAVERSAL_FAST)
+    d, st_d = gpu_render(rt, torch, W, None, nx, ny, ns)
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32)) and torch.equal(c.view(torch.int32), d.view(torch.int32))
+    assert torch.equal(st_c.view(torch.uint8), st_d.view(torch.uint8))
 
 
 # ---------------------------------------------------------------------------------------------------- USE_FP16
@@ -411,9 +434,12 @@ def test_arbitrary_world_hit_records_and_frames(rt, cuda, seed, n, spl):
     S_tree = oracle_of(sp, cam, n, nx, ny, True, spl)
     ref_tree = S_tree.trace(rays, mode=2)
     ref_list = S_tree.trace(rays, mode=1)
-    for name, oct_, mode, ref in (("list", None, None, ref_list), ("scan", O, rt.TRAVERSAL_REFERENCE, ref_tree), ("fast", O, rt.TRAVERSAL_FAST, ref_tree)):
+    for name, oct_, mode, ref in (("list", None, rt.TRAVERSAL_FAST, ref_list), ("list_scan", None, rt.TRAVERSAL_REFERENCE, ref_list),
+                                 ("scan", O, rt.TRAVERSAL_REFERENCE, ref_tree), ("fast", O, rt.TRAVERSAL_FAST, ref_tree)):
         if oct_ is not None:
             oct_.set_traversal(mode)
+        else:
+            W.set_list_traversal(mode)
         d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
         rt.trace_rays(W, oct_, d_rays, nrays, d_out)
         torch.cuda.synchronize()

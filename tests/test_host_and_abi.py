@@ -143,3 +143,26 @@ def test_binary_image_writers(rt, tmp_path):
     raw = (tmp_path / "h.pfm").read_bytes()
     assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(7, 11, 3), fb.astype(np.float16).astype(np.float32))
     assert rt.lib().rt_write_image(b"/nonexistent_dir/x.ppm", 11, 7, fb.ctypes.data, 0, 1) == -3
+
+
+def test_list_traversal_switch_and_candidate_grid_rules(rt):
+    """hitable_list::hit through the candidate grid (rt_world_set_list_traversal): host-side rules only.  The grid serves fp32
+    lists of >= 64 hittable spheres with at most 64 of them outside its range; everything else keeps the list-order scan."""
+    L = rt.lib()
+    assert L.rt_world_set_list_traversal(None, rt.TRAVERSAL_FAST) == -1
+    W = rt.World(500, 64, 36)
+    assert L.rt_world_set_list_traversal(W.h, 7) == -1
+    W.set_list_traversal(rt.TRAVERSAL_REFERENCE).set_list_traversal(rt.TRAVERSAL_FAST)
+    info = W.list_accel_info()
+    assert info["enabled"] and info["large_spheres"] == 3 and info["grid_entries"] >= 484       # the three big spheres are tested directly
+    assert not rt.World(22, 64, 36).list_accel_info()["enabled"]                                 # too small to pay
+    assert not rt.World(500, 64, 36, precision=rt.FP16).list_accel_info()["enabled"]             # the error bounds are binary32 bounds
+    # a list whose spheres mostly lie outside the grid's range: direct tests would dominate
+    sp = W.spheres.copy()
+    sp["center"][100:300, 0] += 40.0
+    far = rt.World(500, 64, 36, spheres=sp, camera=W.camera)
+    assert not far.list_accel_info()["enabled"]
+    sp = W.spheres.copy()
+    sp["center"][100:140, 0] += 40.0
+    near = rt.World(500, 64, 36, spheres=sp, camera=W.camera).list_accel_info()
+    assert near["enabled"] and near["large_spheres"] == 43

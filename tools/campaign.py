@@ -11,6 +11,7 @@ from test_gpu_parity import random_rays, random_world
 bad = 0
 t0 = time.time()
 total_rays = 0
+list_worlds = 0
 for seed in range(24):
     n = [300, 1500, 6000, 20000][seed % 4]
     sp, cam = random_world(rt, 1000 + seed, n, 96, 64, big=3 + seed % 5, air=0.1 + 0.1 * (seed % 4))
@@ -35,6 +36,20 @@ for seed in range(24):
     if diff.size:
         bad += diff.size
         print("world seed %d n=%d: %d differing rays, e.g. %s" % (seed, n, diff.size, rays[diff[0]]))
+    # hitable_list::hit: every sphere in list order against the candidate grid (where the world has one)
+    if n <= 6000 and W.list_accel_info()["enabled"]:
+        outs = []
+        for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_FAST):
+            W.set_list_traversal(mode)
+            o = torch.zeros(nr * 32, dtype=torch.uint8, device="cuda")
+            rt.trace_rays(W, None, d, nr, o); torch.cuda.synchronize()
+            outs.append(o.cpu().numpy().view(np.uint32).reshape(nr, 8))
+        diff = np.nonzero((outs[0] != outs[1]).any(axis=1))[0]
+        total_rays += nr; list_worlds += 1
+        if diff.size:
+            bad += diff.size
+            print("LIST world seed %d n=%d: %d differing rays, e.g. %s" % (seed, n, diff.size, rays[diff[0]]))
+print("list path checked on %d of the worlds" % list_worlds)
 print("random worlds: %d rays, %d mismatches, %.0f s" % (total_rays, bad, time.time() - t0), flush=True)
 
 def frame(n, radius, spl, nx, ny, ns):
@@ -51,6 +66,23 @@ def frame(n, radius, spl, nx, ny, ns):
     if not same:
         bad += 1
 
+def list_frame(n, radius, nx, ny, ns):
+    global bad
+    W = rt.World(n, nx, ny, sphere_radius=radius)
+    res = []
+    for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_FAST):
+        W.set_list_traversal(mode)
+        st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
+        rt.render_init(nx, ny, st); rt.render(fb, nx, ny, ns, W, st, None); torch.cuda.synchronize()
+        res.append((fb, st))
+    same = torch.equal(res[0][0].view(torch.int32), res[1][0].view(torch.int32)) and torch.equal(res[0][1], res[1][1])
+    print("list frame N=%d r=%.2f %dx%dx%d: %s" % (n, radius, nx, ny, ns, "identical" if same else "DIFFERENT"), flush=True)
+    if not same:
+        bad += 1
+
+list_frame(500, 0.1, 1200, 800, 64)
+list_frame(2000, 0.2, 1200, 800, 16)
+list_frame(488, 0.2, 1200, 800, 32)
 frame(500, 0.1, 30, 1200, 800, 64)
 frame(2000, 0.2, 30, 1200, 800, 32)
 frame(8000, 0.1, 30, 1200, 800, 32)
