@@ -224,6 +224,7 @@ int rt_world_upload(rt_world* W) {
     W->dev.geom = (const float4*)W->d_geom; W->dev.mat = (const float4*)W->d_mat; W->dev.kind = (const int32_t*)W->d_kind;
     RT_TRY(hipMalloc((void**)&W->d_queue, kQueueSlots * kQueueStride * sizeof(unsigned int)));
     RT_TRY(hipMemset(W->d_queue, 0, kQueueSlots * kQueueStride * sizeof(unsigned int)));
+    if (W->list_tree && (rc = rt_octree_upload(W->list_tree))) return rc;
     W->uploaded = true;
     return 0;
 }

@@ -548,6 +548,18 @@ def test_calls_captured_in_a_hip_graph(rt, cuda):
             g.replay(); torch.cuda.synchronize()
             assert torch.equal(fb.view(torch.int32), fb0.view(torch.int32)) and torch.equal(st, st0)
 
+    # without an octree (the list through the candidate grid): rt_world_upload has made every device buffer
+    fb0, st0 = gpu_render(rt, torch, W, None, nx, ny, 8)
+    st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rt.render_init(nx, ny, st)
+        rt.render(fb, nx, ny, 8, W, st, None)
+    for _ in range(2):
+        fb.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(fb.view(torch.int32), fb0.view(torch.int32)) and torch.equal(st, st0)
+
 
 @pytest.mark.gpu
 def test_c5_geometry_rows_against_the_oracle(rt, cuda):
