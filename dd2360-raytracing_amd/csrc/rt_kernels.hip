@@ -108,6 +108,9 @@ namespace rt {
 #ifndef RT_LIST_BATCH
 #define RT_LIST_BATCH 8
 #endif
+#ifndef RT_LIST_TREE_COOP
+#define RT_LIST_TREE_COOP 1
+#endif
 #ifndef RT_LIST_COOP_COST
 #define RT_LIST_COOP_COST 16
 #endif
@@ -329,6 +332,43 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
 // passes the slab test, then scans that node's entries.  `closest`/`best` come in holding the ground-sphere result.
 RT_DEV void tree_scan(const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
     const DevTree& T = cold_args()->tree;
+    if (RT_LIST_TREE_COOP && T.n_nodes == 1) {
+        // the list seen as one unbounded node (rt_api.hip build_list_tree): all n_entries spheres are this ray's to test.  Few
+        // rays come here (outside the near zone, ties), so one at a time with lanes = spheres as in closest_list — the smallest
+        // offered t, the lowest entry among equal t, and only if it beats what the ray holds (the ground was tested first)
+        const float4* __restrict__ hot = T.ent_hot;
+        const int n = T.n_entries;
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(live);
+        if ((int)__popcll(todo) * RT_LIST_COOP_COST <= n) {
+            while (todo != 0ull) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                RayF q;
+                q.o.x = bcast(r.o.x, L); q.o.y = bcast(r.o.y, L); q.o.z = bcast(r.o.z, L);
+                q.d.x = bcast(r.d.x, L); q.d.y = bcast(r.d.y, L); q.d.z = bcast(r.d.z, L);
+                const float qa = bcast(a, L);
+                float my_t = FLT_MAX; int my_k = 0x7fffffff;
+                for (int base = 0; base < n; base += 256) {
+                    float4 sv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int k = base + u * 64 + lane; sv[u] = hot[k < n ? k : n - 1]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = base + u * 64 + lane;
+                        if (k < n) {
+                            const float cand = sphere_candidate(q, qa, sv[u]);
+                            if (cand < my_t) { my_t = cand; my_k = k; }
+                        }
+                    }
+                }
+                const float mn = group_min<64>(my_t);
+                const int km = wave_min_int((my_t == mn && my_k != 0x7fffffff) ? my_k : 0x7fffffff);
+                if (lane == L && km != 0x7fffffff && mn < closest) { closest = mn; best = T.ent_id[km]; }
+            }
+            return;
+        }
+    }
     int e_best = -1;
     int node = live ? 0 : T.n_nodes;
     const int n_nodes = T.n_nodes;

@@ -44,10 +44,14 @@ for radius in (0.1, 0.2):
     for n in SIZES:
         W, O, spl = spl_for(n, radius)
         W.upload(); O.upload()
+        W.set_list_traversal(rt.TRAVERSAL_REFERENCE)               # hitable_list::hit as written: every sphere, list order
         t_list = time_render(W, None)
+        W.set_list_traversal(rt.TRAVERSAL_FAST)                    # the default: the list through the candidate grid
+        t_grid = time_render(W, None)
         t_tree = time_render(W, O)
-        rows.append(dict(radius=radius, n=n, spl=spl, list_ms=round(t_list, 3), octree_ms=round(t_tree, 3), speedup=round(t_list / t_tree, 2)))
-        print("r=%.1f N=%5d SPL=%3d  list %8.3f ms  octree %8.3f ms  speed-up %5.2fx  (%.0f / %.0f Msamples/s)" % (
-            radius, n, spl, t_list, t_tree, t_list / t_tree, NX * NY * NS / t_list / 1e3, NX * NY * NS / t_tree / 1e3), flush=True)
+        rows.append(dict(radius=radius, n=n, spl=spl, list_ms=round(t_list, 3), list_grid_ms=round(t_grid, 3), octree_ms=round(t_tree, 3),
+                         speedup=round(t_list / t_tree, 2)))
+        print("r=%.1f N=%5d SPL=%3d  list scan %8.3f ms  list via grid %7.3f ms  octree %7.3f ms  octree vs scan %5.2fx  (%.0f / %.0f / %.0f Msamples/s)" % (
+            radius, n, spl, t_list, t_grid, t_tree, t_list / t_tree, NX * NY * NS / t_list / 1e3, NX * NY * NS / t_grid / 1e3, NX * NY * NS / t_tree / 1e3), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "experiment_r1.json"), "w"), indent=1)
