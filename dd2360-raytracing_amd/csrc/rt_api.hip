@@ -40,7 +40,7 @@ struct rt_world {
     int n = 0;
     bool uploaded = false;
     // hitable_list::hit through the candidate grid: the list as a one-node "tree" (fp32 only; null = plain scan)
-    rt_octree* list_tree = nullptr;
+    rt_octree* list_tree = nullptr; bool list_tree_tried = false;
     int list_traversal = RT_TRAVERSAL_FAST;
     std::vector<float4> h_hot, h_geom, h_mat;
     std::vector<int32_t> h_ids, h_kind;
@@ -76,30 +76,39 @@ template <class V> static int upload(const V& v, void** d) {
     return 0;
 }
 
-static bool hittable(const rt_sphere& s);
-static float radius_squared(const rt_sphere& s, int precision);
 // The list as a tree of ONE node without bounds whose entries are the hittable spheres 1..n-1 in list order: hitTree on
 // it (slot 0 first, then the entries in order, strict "<") is hitable_list::hit, so the fp32 octree kernels — and their
 // candidate grid — serve the list path unchanged.  Null when the grid would not pay or cannot be used.
-static rt_octree* build_list_tree(const rt_sphere* list, int n) {
+static rt_octree* build_list_tree(const rt_world* W) {
     rt_octree* O = new rt_octree();
     O->precision = RT_PRECISION_FP32;
     DevNode d; memset(&d, 0, sizeof(d));
     const float inf = std::numeric_limits<float>::infinity();
     d.lo[0] = d.lo[1] = d.lo[2] = -inf; d.hix = d.hiy = d.hiz = inf;
     d.skip = 1; d.first = 0; d.ref_index = 0;
-    for (int i = 1; i < n; ++i) {
-        if (!hittable(list[i])) continue;
-        O->h_ent_hot.push_back(make_float4(list[i].center[0], list[i].center[1], list[i].center[2], radius_squared(list[i], RT_PRECISION_FP32)));
+    for (int i = 1; i < W->n; ++i) {
+        if (W->h_kind[i] == RT_MAT_NONE) continue;
+        const float4 g = W->h_geom[i];
+        O->h_ent_hot.push_back(make_float4(g.x, g.y, g.z, g.w * g.w));          // radius*radius in float (sphere.h:21)
         O->h_ent_id.push_back(i);
     }
     d.count = (int32_t)O->h_ent_id.size();
     O->h_nodes.push_back(d);
     O->dev.n_nodes = 1; O->dev.n_entries = d.count;
-    if (d.count > 0) build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, n, true);
+    if (d.count > 0) build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, W->n, true);
     // every ray tests the spheres the grid cannot hold: with many of them the scan is the better list path
     if (d.count < 64 || !O->accel.p.enabled || O->accel.p.n_large > 64) { delete O; return nullptr; }
     return O;
+}
+// built on first use (a render or trace call without an octree, rt_world_list_accel_info): a world that is only ever
+// rendered through its octree never pays for it
+static rt_octree* ensure_list_tree(const rt_world* world) {
+    rt_world* W = const_cast<rt_world*>(world);
+    if (!W->list_tree_tried && W->precision == RT_PRECISION_FP32) {
+        W->list_tree_tried = true;
+        try { W->list_tree = build_list_tree(W); } catch (const std::bad_alloc&) { W->list_tree = nullptr; }
+    }
+    return W->list_tree;
 }
 
 static bool valid_partition(rt_partition p) { return p.nparts >= 1 && p.part >= 0 && p.part < p.nparts; }
@@ -193,10 +202,6 @@ int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam
     W->dev.n = num_spheres; W->dev.n_list = (int)hot.size();
     W->dev.ground_valid = hittable(list[0]) ? 1 : 0;
     W->dev.cam = *cam;
-    if (precision == RT_PRECISION_FP32) {
-        try { W->list_tree = build_list_tree(list, num_spheres); }
-        catch (const std::bad_alloc&) { delete W; return RT_ENOMEM; }
-    }
     *out = W;
     return 0;
 }
@@ -209,6 +214,7 @@ int rt_world_set_list_traversal(rt_world* W, int mode) {
 
 int rt_world_list_accel_info(const rt_world* W, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres) {
     if (!W) return RT_EINVAL;
+    ensure_list_tree(W);
     if (enabled) *enabled = W->list_tree != nullptr;
     if (!W->list_tree) { if (grid_dim) *grid_dim = 0; if (cell_size) *cell_size = 0.f; if (grid_entries) *grid_entries = 0; if (large_spheres) *large_spheres = 0; return 0; }
     return rt_octree_accel_info(W->list_tree, grid_dim, cell_size, grid_entries, large_spheres);
@@ -224,7 +230,7 @@ int rt_world_upload(rt_world* W) {
     W->dev.geom = (const float4*)W->d_geom; W->dev.mat = (const float4*)W->d_mat; W->dev.kind = (const int32_t*)W->d_kind;
     RT_TRY(hipMalloc((void**)&W->d_queue, kQueueSlots * kQueueStride * sizeof(unsigned int)));
     RT_TRY(hipMemset(W->d_queue, 0, kQueueSlots * kQueueStride * sizeof(unsigned int)));
-    if (W->list_tree && (rc = rt_octree_upload(W->list_tree))) return rc;
+    if (W->list_tree && (rc = rt_octree_upload(W->list_tree))) return rc;      // (if it has been built already)
     W->uploaded = true;
     return 0;
 }
@@ -391,7 +397,8 @@ int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partiti
 
 // no octree passed: the world's one-node list tree, if it has one and the fast list traversal is selected
 static const rt_octree* list_tree_of(const rt_world* world) {
-    return (world->list_tree && world->list_traversal == RT_TRAVERSAL_FAST) ? world->list_tree : nullptr;
+    if (world->list_traversal != RT_TRAVERSAL_FAST) return nullptr;
+    return ensure_list_tree(world);
 }
 
 static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {

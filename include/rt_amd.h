@@ -126,7 +126,8 @@ int rt_world_upload(rt_world* world);
  * reference's hit records bit for bit (fp32): REFERENCE tests every sphere in list order; FAST (default) tests only the
  * spheres the conservative (x,z) grid of the octree path says the ray can touch (the list seen as one unbounded node:
  * lowest index wins among equal t, exactly like the sequential scan) and falls back to the scan for rays it cannot prove.
- * FP16 worlds, and lists with more than 64 spheres outside the grid's range, always use REFERENCE. */
+ * FP16 worlds, lists of fewer than 64 spheres and lists with more than 64 spheres outside the grid's range always use
+ * REFERENCE.  The grid is built by the first call that needs it (a render/trace without an octree, or the info call). */
 int rt_world_set_list_traversal(rt_world* world, int mode);   /* RT_TRAVERSAL_REFERENCE | RT_TRAVERSAL_FAST */
 int rt_world_list_accel_info(const rt_world* world, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres);
 /* free_world<<<1,1>>> + cudaFree — main.cu:206-219, :464-466. */

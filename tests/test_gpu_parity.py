@@ -548,7 +548,7 @@ def test_calls_captured_in_a_hip_graph(rt, cuda):
             g.replay(); torch.cuda.synchronize()
             assert torch.equal(fb.view(torch.int32), fb0.view(torch.int32)) and torch.equal(st, st0)
 
-    # without an octree (the list through the candidate grid): rt_world_upload has made every device buffer
+    # without an octree (the list through the candidate grid, built and uploaded by the first such call — the direct render here)
     fb0, st0 = gpu_render(rt, torch, W, None, nx, ny, 8)
     st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
     g = torch.cuda.CUDAGraph()
