@@ -150,7 +150,18 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         if (4.0 * (double)radii.size() > 8.0 * g * g) h = std::max(0.05, 0.7 * h);
     }
     const double Rlim = 1.5 * h;                               // spheres with R' above this go to the large list
-    const double half = 11.0 + 2.0 * Rlim + 2.0 * h;
+    // extent: the reference's root box in x and z (every tree sphere's centre lies in it, grown by its radius); a list may
+    // reach further out — as far as the centre bound of the exactness argument lets the grid follow
+    double reach = 11.0;
+    if (list_mode)
+        for (int s = 0; s < n_world; ++s) {
+            if (!in_tree[s]) continue;
+            const float4 g = hot_of[s];
+            const double dc = std::sqrt((double)g.x * g.x + ((double)g.y - 1.0) * ((double)g.y - 1.0) + (double)g.z * g.z);
+            if (!(g.w >= 0.0f) || accel_Rp((double)g.w) > Rlim || !(dc <= kCentreBound)) continue;
+            reach = std::max(reach, std::max(std::fabs((double)g.x), std::fabs((double)g.z)));
+        }
+    const double half = reach + 2.0 * Rlim + 2.0 * h;
     const int G = (int)std::ceil(2.0 * half / h);
     const double g0 = -half;
     p.G = G; p.g0 = (float)g0; p.h = (float)h; p.inv_h = (float)(1.0 / h);
