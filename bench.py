@@ -28,8 +28,10 @@ CONFIGS = {
     "c4": dict(name="C4", nx=1200, ny=800, spp=64, spheres=10000, octree=True, spl=32, flops_per_sample=9.8e3, fp16=True),
 }
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate, spec
-PEAK_UNFUSED_TOPS = 39.3              # 256 CUs x 64 lanes x 2.4 GHz, one unfused fp32 op per lane and cycle — the parity
-                                      # mode's own ceiling (no FMA contraction, no packed fp32); frac_unfused is measured against it
+PEAK_UNFUSED_TOPS = 78.6              # the parity mode's own ceiling (no FMA contraction): PEAK_FP32_VECTOR / 2.  A wave64 fp32 instruction
+                                      # issues in 2 cycles on gfx950 whether packed or not (profiles/micro_pk_rate_r1.txt: v_pk_* run at half
+                                      # the instruction rate of the scalar forms; a mul+add stream sustains 54 T op/s), so packing buys nothing
+                                      # and SURVEY 8d's 39.3 T (one op per lane and cycle on 64 lanes per CU) was a factor 2 too low
 PEAK_HBM_GBS = 8000.0
 
 
