@@ -215,6 +215,13 @@ def main():
                                  "(HIP events on its stream, last <=64 launches); render_call_ms adds the scheduling pre-pass; "
                                  "VALU-bound path, HBM traffic is ~1.7 B/sample"},
         }
+        # the same kernel against the HBM roof (for the record: it is nowhere near it): algorithmic bytes = RNG state in + out
+        # (2 x 48 B) and the vec3 written (12 B) per pixel this rank renders
+        alg_bytes = (96.0 + (6.0 if cfg.get("fp16") else 12.0)) * (local_samples / spp)
+        hbm = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": kernel_name, "achieved": round(hbm, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(hbm / PEAK_HBM_GBS, 6), "traffic": traffic,
+                               "note": "96 B curandState in+out + vec3 out (12 B, fp16: 6 B) per pixel / kernel time; traffic = FETCH_SIZE + WRITE_SIZE per launch (profiles/hbm_traffic.json)"}
         if world == 1 and not args.no_cpu_baseline:
             cores = max(1, min(16, os.cpu_count() or 1))
             v, secs, smp = cpu_baseline(cfg, cores, cfg["octree"], rows=64 if cfg["octree"] else 4, spp=spp if cfg["octree"] else 16)
