@@ -22,6 +22,8 @@ hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const 
 hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y, int nparts, hipStream_t st);
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
+const char* render_kernel_name(bool tree, int mode, const DevAccel& acc);
+const char* render_kernel_name_h(bool tree, int mode);
 #ifdef RT_STATS
 hipError_t read_stats(unsigned long long* out, int reset);
 hipError_t read_wave_dbg(unsigned long long* out);
@@ -33,47 +35,78 @@ using namespace rt;
 #define RT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // Handles keep their host staging copy; device buffers are created by rt_world_upload / rt_octree_upload
-// (called implicitly by the first render/trace that uses the handle).
+// (called implicitly by the first render/trace that uses the handle).  A handle passed as `const` to a compute call stays
+// logically constant: what such a call may create lazily (device copies, the list grid, the default render context) lives
+// behind a pointer in a `Lazy` block of its own.
 struct rt_octree;
+
+// Per-launch state of rt_render: work counters, scheduling workspace, timing events.  One context serves one launch at a
+// time: calls on the same context are ordered by the library (an event recorded behind the render kernel, which the next
+// call's stream waits for before it touches the workspace), so two streams sharing a context serialise instead of racing;
+// give concurrent frames a context each (rt_render_ctx_create).
+struct rt_render_ctx {
+    // work counters of the persistent render kernel: a ring of slots (one per launch, 64 B apart), zeroed on the stream
+    unsigned int* d_queue = nullptr; unsigned launches = 0;
+    // scheduling workspace (tile costs, hand-out order, long-chain flags and list), grown on demand
+    int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
+    // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_render_ctx_times
+    hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
+    // ordering of successive launches that share this context
+    hipEvent_t done = nullptr; hipStream_t last_stream = nullptr; bool has_done = false;
+};
+static const unsigned kQueueSlots = 64, kQueueStride = 16;
+
 struct rt_world {
     int precision = RT_PRECISION_FP32;
     int n = 0;
-    bool uploaded = false;
-    // hitable_list::hit through the candidate grid: the list as a one-node "tree" (fp32 only; null = plain scan)
-    rt_octree* list_tree = nullptr; bool list_tree_tried = false;
-    int list_traversal = RT_TRAVERSAL_FAST;
     std::vector<float4> h_hot, h_geom, h_mat;
     std::vector<int32_t> h_ids, h_kind;
-    DevScene dev{};
-    void* d_list_hot = nullptr; void* d_list_id = nullptr; void* d_geom = nullptr; void* d_mat = nullptr; void* d_kind = nullptr;
-    // work counters of the persistent render kernel: a ring of slots (one per launch, 64 B apart) so that launches
-    // queued on different streams never share one
-    unsigned int* d_queue = nullptr; unsigned launches = 0;
-    // scheduling workspace of rt_render (tile costs and hand-out order), grown on demand
-    // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_world_render_times
-    hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
-    int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
+    int list_traversal = RT_TRAVERSAL_FAST;
+    struct Lazy {
+        bool uploaded = false;
+        DevScene dev{};
+        void* d_list_hot = nullptr; void* d_list_id = nullptr; void* d_geom = nullptr; void* d_mat = nullptr; void* d_kind = nullptr;
+        // hitable_list::hit through the candidate grid: the list as a one-node "tree" (fp32 only; null = plain scan)
+        rt_octree* list_tree = nullptr; bool list_tree_tried = false;
+        rt_render_ctx ctx;                      // the context rt_render / rt_render_progressive use
+    };
+    Lazy* z = nullptr;
 };
-static const unsigned kQueueSlots = 64, kQueueStride = 16;
 
 struct rt_octree {
     int precision = RT_PRECISION_FP32;
     Octree* host = nullptr;
-    bool uploaded = false;
     std::vector<DevNode> h_nodes; std::vector<float4> h_ent_hot; std::vector<int32_t> h_ent_id;
     AccelHost accel;
     int traversal = RT_TRAVERSAL_FAST;
-    DevTree dev{};
-    void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
-    void* d_acc[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // rt_octree_upload: large_hot, large_brick, cs, hot, brick, memb_start, memb_cell, -, cellnode, bits_index, cellbits
+    struct Lazy {
+        bool uploaded = false;
+        DevTree dev{};
+        void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
+        void* d_acc[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // large_hot, large_brick, cs, hot, brick, memb_start, memb_cell, -, cellnode, bits_index, cellbits
+    };
+    Lazy* z = nullptr;
+    int n_nodes = 0, n_entries = 0;
 };
 
+// device copy of a host vector into *d.  A buffer that exists already (an earlier upload attempt got that far) is kept;
+// on failure nothing allocated here is left behind.
 template <class V> static int upload(const V& v, void** d) {
-    *d = nullptr;
+    if (*d) return 0;
     const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(typename V::value_type);
-    RT_TRY(hipMalloc(d, bytes));
-    if (!v.empty()) RT_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(typename V::value_type), hipMemcpyHostToDevice));
+    void* p = nullptr;
+    RT_TRY(hipMalloc(&p, bytes));
+    if (!v.empty()) {
+        const hipError_t e = hipMemcpy(p, v.data(), v.size() * sizeof(typename V::value_type), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+    }
+    *d = p;
     return 0;
+}
+static int free_all(void** bufs, int n) {
+    int rc = 0;
+    for (int k = 0; k < n; ++k) if (bufs[k]) { const hipError_t e = hipFree(bufs[k]); if (e != hipSuccess && !rc) rc = (int)e; bufs[k] = nullptr; }
+    return rc;
 }
 
 // The list as a tree of ONE node without bounds whose entries are the hittable spheres 1..n-1 in list order: hitTree on
@@ -81,6 +114,7 @@ template <class V> static int upload(const V& v, void** d) {
 // candidate grid — serve the list path unchanged.  Null when the grid would not pay or cannot be used.
 static rt_octree* build_list_tree(const rt_world* W) {
     rt_octree* O = new rt_octree();
+    O->z = new rt_octree::Lazy();
     O->precision = RT_PRECISION_FP32;
     DevNode d; memset(&d, 0, sizeof(d));
     const float inf = std::numeric_limits<float>::infinity();
@@ -94,21 +128,21 @@ static rt_octree* build_list_tree(const rt_world* W) {
     }
     d.count = (int32_t)O->h_ent_id.size();
     O->h_nodes.push_back(d);
-    O->dev.n_nodes = 1; O->dev.n_entries = d.count;
+    O->n_nodes = 1; O->n_entries = d.count;
     if (d.count > 0) build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, W->n, true);
     // every ray tests the spheres the grid cannot hold: with many of them the scan is the better list path
-    if (d.count < 64 || !O->accel.p.enabled || O->accel.p.n_large > 64) { delete O; return nullptr; }
+    if (d.count < 64 || !O->accel.p.enabled || O->accel.p.n_large > 64) { delete O->z; delete O; return nullptr; }
     return O;
 }
 // built on first use (a render or trace call without an octree, rt_world_list_accel_info): a world that is only ever
 // rendered through its octree never pays for it
-static rt_octree* ensure_list_tree(const rt_world* world) {
-    rt_world* W = const_cast<rt_world*>(world);
-    if (!W->list_tree_tried && W->precision == RT_PRECISION_FP32) {
-        W->list_tree_tried = true;
-        try { W->list_tree = build_list_tree(W); } catch (const std::bad_alloc&) { W->list_tree = nullptr; }
+static rt_octree* ensure_list_tree(const rt_world* W) {
+    rt_world::Lazy& Z = *W->z;
+    if (!Z.list_tree_tried && W->precision == RT_PRECISION_FP32) {
+        Z.list_tree_tried = true;
+        try { Z.list_tree = build_list_tree(W); } catch (const std::bad_alloc&) { Z.list_tree = nullptr; }
     }
-    return W->list_tree;
+    return Z.list_tree;
 }
 
 static bool valid_partition(rt_partition p) { return p.nparts >= 1 && p.part >= 0 && p.part < p.nparts; }
@@ -154,6 +188,7 @@ const char* rt_error_string(int code) {
         case RT_ENOMEM: return "out of host memory";
         case RT_EIO: return "i/o error";
         case RT_ENOTSUP: return "not supported";
+        case RT_ECOMM: return "multi-GPU exchange failed";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -188,6 +223,8 @@ int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam
     *out = nullptr;
     rt_world* W = new (std::nothrow) rt_world();
     if (!W) return RT_ENOMEM;
+    W->z = new (std::nothrow) rt_world::Lazy();
+    if (!W->z) { delete W; return RT_ENOMEM; }
     W->precision = precision; W->n = num_spheres;
     std::vector<float4>& hot = W->h_hot; std::vector<float4>& geom = W->h_geom; std::vector<float4>& mat = W->h_mat;
     std::vector<int32_t>& ids = W->h_ids; std::vector<int32_t>& kind = W->h_kind;
@@ -199,9 +236,9 @@ int rt_world_create(const rt_sphere* list, int num_spheres, const rt_camera* cam
         kind[i] = s.material;
         if (hittable(s)) { hot.push_back(make_float4(s.center[0], s.center[1], s.center[2], radius_squared(s, precision))); ids.push_back(i); }
     }
-    W->dev.n = num_spheres; W->dev.n_list = (int)hot.size();
-    W->dev.ground_valid = hittable(list[0]) ? 1 : 0;
-    W->dev.cam = *cam;
+    W->z->dev.n = num_spheres; W->z->dev.n_list = (int)hot.size();
+    W->z->dev.ground_valid = hittable(list[0]) ? 1 : 0;
+    W->z->dev.cam = *cam;
     *out = W;
     return 0;
 }
@@ -214,34 +251,113 @@ int rt_world_set_list_traversal(rt_world* W, int mode) {
 
 int rt_world_list_accel_info(const rt_world* W, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres) {
     if (!W) return RT_EINVAL;
-    ensure_list_tree(W);
-    if (enabled) *enabled = W->list_tree != nullptr;
-    if (!W->list_tree) { if (grid_dim) *grid_dim = 0; if (cell_size) *cell_size = 0.f; if (grid_entries) *grid_entries = 0; if (large_spheres) *large_spheres = 0; return 0; }
-    return rt_octree_accel_info(W->list_tree, grid_dim, cell_size, grid_entries, large_spheres);
+    rt_octree* LT = ensure_list_tree(W);
+    if (enabled) *enabled = LT != nullptr;
+    if (!LT) { if (grid_dim) *grid_dim = 0; if (cell_size) *cell_size = 0.f; if (grid_entries) *grid_entries = 0; if (large_spheres) *large_spheres = 0; return 0; }
+    return rt_octree_accel_info(LT, grid_dim, cell_size, grid_entries, large_spheres);
 }
 
-int rt_world_upload(rt_world* W) {
-    if (!W) return RT_EINVAL;
-    if (W->uploaded) return 0;
-    int rc;
-    if ((rc = upload(W->h_hot, &W->d_list_hot)) || (rc = upload(W->h_ids, &W->d_list_id)) || (rc = upload(W->h_geom, &W->d_geom)) ||
-        (rc = upload(W->h_mat, &W->d_mat)) || (rc = upload(W->h_kind, &W->d_kind))) return rc;
-    W->dev.list_hot = (const float4*)W->d_list_hot; W->dev.list_id = (const int32_t*)W->d_list_id;
-    W->dev.geom = (const float4*)W->d_geom; W->dev.mat = (const float4*)W->d_mat; W->dev.kind = (const int32_t*)W->d_kind;
-    RT_TRY(hipMalloc((void**)&W->d_queue, kQueueSlots * kQueueStride * sizeof(unsigned int)));
-    RT_TRY(hipMemset(W->d_queue, 0, kQueueSlots * kQueueStride * sizeof(unsigned int)));
-    if (W->list_tree && (rc = rt_octree_upload(W->list_tree))) return rc;      // (if it has been built already)
-    W->uploaded = true;
+// ---- render contexts ---------------------------------------------------------------------------------------------
+static int ctx_prepare(rt_render_ctx& C) {          // device counters and events; not inside a stream capture
+    if (!C.d_queue) {
+        void* q = nullptr;
+        RT_TRY(hipMalloc(&q, kQueueSlots * kQueueStride * sizeof(unsigned int)));
+        const hipError_t e = hipMemset(q, 0, kQueueSlots * kQueueStride * sizeof(unsigned int));
+        if (e != hipSuccess) { (void)hipFree(q); return (int)e; }
+        C.d_queue = (unsigned int*)q;
+    }
+    if (!C.ev_ready) {
+        for (int k = 0; k < 64; ++k) {
+            if (!C.ev0[k]) RT_TRY(hipEventCreate(&C.ev0[k]));
+            if (!C.ev1[k]) RT_TRY(hipEventCreate(&C.ev1[k]));
+        }
+        if (!C.done) RT_TRY(hipEventCreateWithFlags(&C.done, hipEventDisableTiming));
+        C.ev_ready = true;
+    }
     return 0;
 }
+// the scheduling workspace for frames of up to `tiles` local tiles.  Growing it frees the old one: hipFree waits for the
+// device, so launches still queued on it finish first.
+static int ctx_reserve(rt_render_ctx& C, int64_t tiles) {
+    if (C.sched_tiles >= tiles) return 0;
+    void* old[4] = {C.d_cost, C.d_order, C.d_flags, C.d_long};
+    C.d_cost = nullptr; C.d_order = nullptr; C.d_flags = nullptr; C.d_long = nullptr; C.sched_tiles = 0;
+    int rc = free_all(old, 4);
+    if (rc) return rc;
+    void* nw[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[4] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 64, sizeof(unsigned int) * (size_t)tiles * 64};
+    for (int k = 0; k < 4; ++k) {
+        const hipError_t e = hipMalloc(&nw[k], bytes[k]);
+        if (e != hipSuccess) { (void)free_all(nw, 4); return (int)e; }
+    }
+    C.d_cost = (int*)nw[0]; C.d_order = (unsigned int*)nw[1]; C.d_flags = (unsigned char*)nw[2]; C.d_long = (unsigned int*)nw[3];
+    C.sched_tiles = tiles;
+    return 0;
+}
+static int ctx_release(rt_render_ctx& C) {
+    void* bufs[5] = {C.d_queue, C.d_cost, C.d_order, C.d_flags, C.d_long};
+    const int rc = free_all(bufs, 5);
+    C.d_queue = nullptr; C.d_cost = nullptr; C.d_order = nullptr; C.d_flags = nullptr; C.d_long = nullptr; C.sched_tiles = 0;
+    for (int k = 0; k < 64; ++k) { if (C.ev0[k]) (void)hipEventDestroy(C.ev0[k]); if (C.ev1[k]) (void)hipEventDestroy(C.ev1[k]); C.ev0[k] = nullptr; C.ev1[k] = nullptr; }
+    if (C.done) (void)hipEventDestroy(C.done);
+    C.done = nullptr; C.ev_ready = false; C.has_done = false; C.ev_count = 0;
+    return rc;
+}
+
+int rt_render_ctx_create(rt_render_ctx** out) {
+    if (!out) return RT_EINVAL;
+    *out = nullptr;
+    rt_render_ctx* C = new (std::nothrow) rt_render_ctx();
+    if (!C) return RT_ENOMEM;
+    const int rc = ctx_prepare(*C);
+    if (rc) { (void)ctx_release(*C); delete C; return rc; }
+    *out = C;
+    return 0;
+}
+int rt_render_ctx_reserve(rt_render_ctx* C, int max_x, int max_y, rt_partition part) {
+    if (!C || max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
+    const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
+    const int rc = ctx_prepare(*C);
+    return rc ? rc : ctx_reserve(*C, (tiles - part.part + part.nparts - 1) / part.nparts);
+}
+int rt_render_ctx_destroy(rt_render_ctx* C) {
+    if (!C) return 0;
+    const int rc = ctx_release(*C);
+    delete C;
+    return rc;
+}
+
+static int world_upload(const rt_world* W) {
+    rt_world::Lazy& Z = *W->z;
+    if (Z.uploaded) return 0;
+    int rc;
+    if ((rc = upload(W->h_hot, &Z.d_list_hot)) || (rc = upload(W->h_ids, &Z.d_list_id)) || (rc = upload(W->h_geom, &Z.d_geom)) ||
+        (rc = upload(W->h_mat, &Z.d_mat)) || (rc = upload(W->h_kind, &Z.d_kind))) {
+        void* bufs[5] = {Z.d_list_hot, Z.d_list_id, Z.d_geom, Z.d_mat, Z.d_kind};       // nothing half-made stays behind
+        (void)free_all(bufs, 5);
+        Z.d_list_hot = Z.d_list_id = Z.d_geom = Z.d_mat = Z.d_kind = nullptr;
+        return rc;
+    }
+    Z.dev.list_hot = (const float4*)Z.d_list_hot; Z.dev.list_id = (const int32_t*)Z.d_list_id;
+    Z.dev.geom = (const float4*)Z.d_geom; Z.dev.mat = (const float4*)Z.d_mat; Z.dev.kind = (const int32_t*)Z.d_kind;
+    if ((rc = ctx_prepare(Z.ctx))) return rc;
+    if (Z.list_tree && (rc = rt_octree_upload(Z.list_tree))) return rc;      // (if it has been built already)
+    Z.uploaded = true;
+    return 0;
+}
+int rt_world_upload(rt_world* W) { return W ? world_upload(W) : RT_EINVAL; }
 
 int rt_free_world(rt_world* W) {
     if (!W) return 0;
     int rc = 0;
-    if (W->list_tree) { rc = rt_free_octree(W->list_tree); W->list_tree = nullptr; }
-    void* bufs[10] = {W->d_list_hot, W->d_list_id, W->d_geom, W->d_mat, W->d_kind, W->d_queue, W->d_cost, W->d_order, W->d_flags, W->d_long};
-    for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
-    if (W->ev_ready) for (int k = 0; k < 64; ++k) { (void)hipEventDestroy(W->ev0[k]); (void)hipEventDestroy(W->ev1[k]); }
+    if (W->z) {
+        rt_world::Lazy& Z = *W->z;
+        if (Z.list_tree) { rc = rt_free_octree(Z.list_tree); Z.list_tree = nullptr; }
+        void* bufs[5] = {Z.d_list_hot, Z.d_list_id, Z.d_geom, Z.d_mat, Z.d_kind};
+        const int r2 = free_all(bufs, 5); if (!rc) rc = r2;
+        const int r3 = ctx_release(Z.ctx); if (!rc) rc = r3;
+        delete W->z;
+    }
     delete W;
     return rc;
 }
@@ -279,12 +395,14 @@ int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_lea
     *out = nullptr;
     rt_octree* O = new (std::nothrow) rt_octree();
     if (!O) return RT_ENOMEM;
+    O->z = new (std::nothrow) rt_octree::Lazy();
+    if (!O->z) { delete O; return RT_ENOMEM; }
     O->precision = precision;
     try {
         O->host = (precision == RT_PRECISION_FP16) ? buildOctree<half_t>(list, num_hitables, spheres_per_leaf)
                                                    : buildOctree<float>(list, num_hitables, spheres_per_leaf);
         flatten(*O->host, list, precision, 0, O->h_nodes, O->h_ent_hot, O->h_ent_id);
-        O->dev.n_nodes = (int)O->h_nodes.size(); O->dev.n_entries = (int)O->h_ent_id.size();
+        O->n_nodes = (int)O->h_nodes.size(); O->n_entries = (int)O->h_ent_id.size();
         build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, num_hitables);
         if (precision != RT_PRECISION_FP32) O->accel.p.enabled = 0;      // the error bounds behind the grid are binary32 bounds
     } catch (const std::bad_alloc&) { rt_free_octree(O); return RT_ENOMEM; }
@@ -292,9 +410,9 @@ int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_lea
     return 0;
 }
 
-int rt_octree_upload(rt_octree* O) {
-    if (!O) return RT_EINVAL;
-    if (O->uploaded) return 0;
+static int octree_upload(const rt_octree* O) {
+    rt_octree::Lazy& Z = *O->z;
+    if (Z.uploaded) return 0;
     int rc;
     if (O->precision == RT_PRECISION_FP16) {
         // binary16 trees: the bucket entries as four halves (cx, cy, cz, r^2) in 8 bytes — the values are binary16 numbers
@@ -304,24 +422,31 @@ int rt_octree_upload(rt_octree* O) {
             const float4 v = O->h_ent_hot[k];
             packed[k] = make_uint2((uint32_t)half_t(v.x).bits | ((uint32_t)half_t(v.y).bits << 16), (uint32_t)half_t(v.z).bits | ((uint32_t)half_t(v.w).bits << 16));
         }
-        if ((rc = upload(packed, &O->d_ent_hot))) return rc;
-    } else if ((rc = upload(O->h_ent_hot, &O->d_ent_hot))) return rc;
-    if ((rc = upload(O->h_nodes, &O->d_nodes)) || (rc = upload(O->h_ent_id, &O->d_ent_id))) return rc;
-    O->dev.nodes4 = (const float4*)O->d_nodes; O->dev.ent_hot = (const float4*)O->d_ent_hot; O->dev.ent_id = (const int32_t*)O->d_ent_id;
-    AccelHost& A = O->accel;
-    if ((rc = upload(A.large_hot, &O->d_acc[0])) || (rc = upload(A.large_brick, &O->d_acc[1])) || (rc = upload(A.cs, &O->d_acc[2])) ||
-        (rc = upload(A.hot, &O->d_acc[3])) || (rc = upload(A.brick, &O->d_acc[4])) || (rc = upload(A.memb_start, &O->d_acc[5])) ||
-        (rc = upload(A.memb_cell, &O->d_acc[6])) || (rc = upload(A.cellnode, &O->d_acc[8])) ||
-        (rc = upload(A.bits_index, &O->d_acc[9])) || (rc = upload(A.cellbits, &O->d_acc[10]))) return rc;
-    DevAccel& p = A.p;
-    p.large_hot = (const float4*)O->d_acc[0]; p.large_brick = (const float4*)O->d_acc[1];
-    p.cs = (const int32_t*)O->d_acc[2]; p.hot = (const float4*)O->d_acc[3]; p.brick = (const float4*)O->d_acc[4];
-    p.memb_start = (const int32_t*)O->d_acc[5]; p.memb_cell = (const int32_t*)O->d_acc[6]; p.cellnode = (const int32_t*)O->d_acc[8];
-    p.bits_index = (const int32_t*)O->d_acc[9]; p.cellbits = (const uint32_t*)O->d_acc[10];
-    O->dev.acc = p;
-    O->uploaded = true;
+        rc = upload(packed, &Z.d_ent_hot);
+    } else rc = upload(O->h_ent_hot, &Z.d_ent_hot);
+    const AccelHost& A = O->accel;
+    if (rc || (rc = upload(O->h_nodes, &Z.d_nodes)) || (rc = upload(O->h_ent_id, &Z.d_ent_id)) ||
+        (rc = upload(A.large_hot, &Z.d_acc[0])) || (rc = upload(A.large_brick, &Z.d_acc[1])) || (rc = upload(A.cs, &Z.d_acc[2])) ||
+        (rc = upload(A.hot, &Z.d_acc[3])) || (rc = upload(A.brick, &Z.d_acc[4])) || (rc = upload(A.memb_start, &Z.d_acc[5])) ||
+        (rc = upload(A.memb_cell, &Z.d_acc[6])) || (rc = upload(A.cellnode, &Z.d_acc[8])) ||
+        (rc = upload(A.bits_index, &Z.d_acc[9])) || (rc = upload(A.cellbits, &Z.d_acc[10]))) {
+        void* bufs[3] = {Z.d_nodes, Z.d_ent_hot, Z.d_ent_id};                            // nothing half-made stays behind
+        (void)free_all(bufs, 3); (void)free_all(Z.d_acc, 12);
+        Z.d_nodes = Z.d_ent_hot = Z.d_ent_id = nullptr;
+        return rc;
+    }
+    Z.dev.n_nodes = O->n_nodes; Z.dev.n_entries = O->n_entries;
+    Z.dev.nodes4 = (const float4*)Z.d_nodes; Z.dev.ent_hot = (const float4*)Z.d_ent_hot; Z.dev.ent_id = (const int32_t*)Z.d_ent_id;
+    DevAccel p = A.p;
+    p.large_hot = (const float4*)Z.d_acc[0]; p.large_brick = (const float4*)Z.d_acc[1];
+    p.cs = (const int32_t*)Z.d_acc[2]; p.hot = (const float4*)Z.d_acc[3]; p.brick = (const float4*)Z.d_acc[4];
+    p.memb_start = (const int32_t*)Z.d_acc[5]; p.memb_cell = (const int32_t*)Z.d_acc[6]; p.cellnode = (const int32_t*)Z.d_acc[8];
+    p.bits_index = (const int32_t*)Z.d_acc[9]; p.cellbits = (const uint32_t*)Z.d_acc[10];
+    Z.dev.acc = p;
+    Z.uploaded = true;
     return 0;
 }
+int rt_octree_upload(rt_octree* O) { return O ? octree_upload(O) : RT_EINVAL; }
 
 // RT_TRAVERSAL_REFERENCE: scan every bucket of every visited level-3 node, exactly like traverseTree.
 // RT_TRAVERSAL_FAST (default): same hit records through the candidate-culling grid (fp32 only; fp16 always scans).
@@ -351,9 +476,12 @@ int rt_octree_flat_info(const rt_octree* O, int* n_nodes, int* n_entries) {
 int rt_free_octree(rt_octree* O) {
     if (!O) return 0;
     int rc = 0;
-    void* bufs[3] = {O->d_nodes, O->d_ent_hot, O->d_ent_id};
-    for (void* b : bufs) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
-    for (void* b : O->d_acc) if (b) { hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
+    if (O->z) {
+        void* bufs[3] = {O->z->d_nodes, O->z->d_ent_hot, O->z->d_ent_id};
+        rc = free_all(bufs, 3);
+        const int r2 = free_all(O->z->d_acc, 12); if (!rc) rc = r2;
+        delete O->z;
+    }
     delete O->host;      // the reference frees a new'ed Octree with free() (main.cu:473); here new/delete match
     delete O;
     return rc;
@@ -401,89 +529,133 @@ static const rt_octree* list_tree_of(const rt_world* world) {
     return ensure_list_tree(world);
 }
 
-static int render_common(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
+// what a render / trace call needs on the device: the world, and the tree it walks (the caller's octree, or the world's list tree)
+static int ensure_on_device(const rt_world* world, const rt_octree*& d_octree) {
+    if (!d_octree) d_octree = list_tree_of(world);                    // hitable_list::hit through the candidate grid
+    int rc = world_upload(world);
+    if (!rc && d_octree) rc = octree_upload(d_octree);
+    return rc;
+}
+static DevTree tree_args(const rt_octree* d_octree) {
+    DevTree T;
+    if (d_octree) { T = d_octree->z->dev; T.acc.enabled = T.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
+    else memset(&T, 0, sizeof(T));
+    return T;
+}
+static bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
     if (!world || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
     if (rt_part_pixels(max_x, max_y, part) == 0) return 0;            // a part without tiles (more parts than tiles): nothing to do
     if (!fb || !d_rand_state) return RT_EINVAL;
-    if (!d_octree) d_octree = list_tree_of(world);                    // hitable_list::hit through the candidate grid
-    int rc = rt_world_upload(const_cast<rt_world*>(world));
-    if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
+    const hipStream_t st = (hipStream_t)stream;
+    const bool cap = capturing(st);
+    int rc = ensure_on_device(world, d_octree);
+    rt_render_ctx& C = ctx ? *ctx : world->z->ctx;
+    if (!rc && !cap) rc = ctx_prepare(C);
     if (rc) return rc;
+    if (!C.d_queue) return RT_EINVAL;                                  // a context first used inside a capture: prepare it before (rt_render_ctx_reserve)
     RenderArgs A;
     A.fb = fb; A.rand_state = d_rand_state; A.max_x = max_x; A.max_y = max_y; A.ns = ns;
     A.tiles_x = (max_x + 7) / 8; A.tiles_y = (max_y + 7) / 8;
     A.part = part.part; A.nparts = part.nparts;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
     A.n_local_tiles = (tiles - part.part + part.nparts - 1) / part.nparts;
-    A.scene = world->dev;
-    rt_world* wm = const_cast<rt_world*>(world);
-    A.queue = wm->d_queue + (size_t)(wm->launches++ % kQueueSlots) * kQueueStride;
-    RT_TRY(launch_zero_counters(A.queue, 4, (hipStream_t)stream));
-    if (d_octree) { A.tree = d_octree->dev; A.tree.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
-    else memset(&A.tree, 0, sizeof(A.tree));
+    A.scene = world->z->dev;
+    A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
-    if (!wm->ev_ready) {
-        for (int k = 0; k < 64; ++k) { RT_TRY(hipEventCreate(&wm->ev0[k])); RT_TRY(hipEventCreate(&wm->ev1[k])); }
-        wm->ev_ready = true;
+    const bool sched = world->precision == RT_PRECISION_FP32 && mode == 0 && ns >= 4;
+    // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame: call rt_render
+    // (or rt_render_ctx_reserve) once before capturing it into a hipGraph.
+    if (sched && C.sched_tiles < A.n_local_tiles) {
+        if (cap) return RT_EINVAL;
+        if ((rc = ctx_reserve(C, A.n_local_tiles))) return rc;
     }
-    const unsigned ek = wm->ev_head % 64u;
-    if (world->precision == RT_PRECISION_FP16) {
-        RT_TRY(hipEventRecord(wm->ev0[ek], (hipStream_t)stream));
-        RT_TRY(launch_render_h(A, d_octree != nullptr, mode, (hipStream_t)stream));
-        RT_TRY(hipEventRecord(wm->ev1[ek], (hipStream_t)stream));
-        wm->ev_head++; if (wm->ev_count < 64) wm->ev_count++;
-        return 0;
-    }
-    if (mode == 0 && ns >= 4) {
-        // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame:
-        // call rt_render once before capturing it into a hipGraph.
-        if (wm->sched_tiles < A.n_local_tiles) {
-            if (wm->d_cost) { RT_TRY(hipFree(wm->d_cost)); wm->d_cost = nullptr; }
-            if (wm->d_order) { RT_TRY(hipFree(wm->d_order)); wm->d_order = nullptr; }
-            if (wm->d_flags) { RT_TRY(hipFree(wm->d_flags)); wm->d_flags = nullptr; }
-            if (wm->d_long) { RT_TRY(hipFree(wm->d_long)); wm->d_long = nullptr; }
-            wm->sched_tiles = 0;
-            RT_TRY(hipMalloc((void**)&wm->d_cost, sizeof(int) * (size_t)A.n_local_tiles));
-            RT_TRY(hipMalloc((void**)&wm->d_order, sizeof(unsigned int) * (size_t)A.n_local_tiles));
-            RT_TRY(hipMalloc((void**)&wm->d_flags, (size_t)A.n_local_tiles * 64));
-            RT_TRY(hipMalloc((void**)&wm->d_long, sizeof(unsigned int) * (size_t)A.n_local_tiles * 64));
-            wm->sched_tiles = A.n_local_tiles;
-        }
+    // launches sharing a context are ordered: the previous render kernel has finished before this call's kernels touch the
+    // counters ring's neighbours and the workspace (a no-op on the same stream)
+    if (!cap && C.has_done && C.last_stream != st) RT_TRY(hipStreamWaitEvent(st, C.done, 0));
+    A.queue = C.d_queue + (size_t)(C.launches++ % kQueueSlots) * kQueueStride;
+    RT_TRY(launch_zero_counters(A.queue, 4, st));
+    if (sched) {
         const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long
-        RT_TRY(launch_tile_order(A, d_octree != nullptr, wm->d_cost, wm->d_order, classify ? wm->d_flags : nullptr, classify ? wm->d_long : nullptr, (hipStream_t)stream));
-        A.order = wm->d_order;
-        if (classify) { A.long_flag = wm->d_flags; A.long_list = wm->d_long; }
+        RT_TRY(launch_tile_order(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
+        A.order = C.d_order;
+        if (classify) { A.long_flag = C.d_flags; A.long_list = C.d_long; }
     }
-    RT_TRY(hipEventRecord(wm->ev0[ek], (hipStream_t)stream));
-    RT_TRY(launch_render(A, d_octree != nullptr, mode, (hipStream_t)stream));
-    RT_TRY(hipEventRecord(wm->ev1[ek], (hipStream_t)stream));
-    wm->ev_head++; if (wm->ev_count < 64) wm->ev_count++;
+    // timing events only outside a capture (recorded into a graph they would never be "recorded" for hipEventElapsedTime)
+    const unsigned ek = C.ev_head % 64u;
+    if (!cap) RT_TRY(hipEventRecord(C.ev0[ek], st));
+    if (world->precision == RT_PRECISION_FP16) RT_TRY(launch_render_h(A, d_octree != nullptr, mode, st));
+    else RT_TRY(launch_render(A, d_octree != nullptr, mode, st));
+    if (!cap) {
+        RT_TRY(hipEventRecord(C.ev1[ek], st));
+        C.ev_head++; if (C.ev_count < 64) C.ev_count++;
+        RT_TRY(hipEventRecord(C.done, st));
+        C.has_done = true; C.last_stream = st;
+    }
     return 0;
 }
 
-int rt_world_render_times(rt_world* W, float* ms_out, int max, int* count) {
-    if (!W || !ms_out || !count || max < 0) return RT_EINVAL;
+static int ctx_times(rt_render_ctx& C, float* ms_out, int max, int* count) {
     int n = 0;
-    const unsigned have = W->ev_count;
+    const unsigned have = C.ev_count;
     for (unsigned k = 0; k < have && n < max; ++k) {
-        const unsigned slot = (W->ev_head - have + k) % 64u;
-        RT_TRY(hipEventSynchronize(W->ev1[slot]));
+        const unsigned slot = (C.ev_head - have + k) % 64u;
+        RT_TRY(hipEventSynchronize(C.ev1[slot]));
         float ms = 0.f;
-        RT_TRY(hipEventElapsedTime(&ms, W->ev0[slot], W->ev1[slot]));
+        RT_TRY(hipEventElapsedTime(&ms, C.ev0[slot], C.ev1[slot]));
         ms_out[n++] = ms;
     }
     *count = n;
-    W->ev_count = 0;
+    C.ev_count = 0;
     return 0;
+}
+int rt_world_render_times(rt_world* W, float* ms_out, int max, int* count) {
+    if (!W || !ms_out || !count || max < 0) return RT_EINVAL;
+    return ctx_times(W->z->ctx, ms_out, max, count);
+}
+int rt_render_ctx_times(rt_render_ctx* C, float* ms_out, int max, int* count) {
+    if (!C || !ms_out || !count || max < 0) return RT_EINVAL;
+    return ctx_times(*C, ms_out, max, count);
 }
 
 int rt_render(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
-    return render_common(fb, max_x, max_y, ns, world, d_rand_state, d_octree, part, stream, 0);
+    return render_common(nullptr, fb, max_x, max_y, ns, world, d_rand_state, d_octree, part, stream, 0);
+}
+int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
+    return render_common(nullptr, fb, max_x, max_y, current_sample, world, d_rand_state, d_octree, part, stream, 1);
+}
+int rt_render_on(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
+    if (!ctx) return RT_EINVAL;
+    return render_common(ctx, fb, max_x, max_y, ns, world, d_rand_state, d_octree, part, stream, 0);
+}
+int rt_render_progressive_on(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int current_sample, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
+    if (!ctx) return RT_EINVAL;
+    return render_common(ctx, fb, max_x, max_y, current_sample, world, d_rand_state, d_octree, part, stream, 1);
 }
 
-int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream) {
-    return render_common(fb, max_x, max_y, current_sample, world, d_rand_state, d_octree, part, stream, 1);
+// the kernel rt_render (mode 0) / rt_render_progressive (mode 1) launches for this world and tree — the library's own
+// selection rule, for profiles and bench lines (rocprofv3 shows the same name)
+int rt_render_kernel_name(const rt_world* world, const rt_octree* d_octree, int mode, char* out, int cap) {
+    if (!world || !out || cap <= 0 || (mode != 0 && mode != 1)) return RT_EINVAL;
+    if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
+    if (!d_octree) d_octree = list_tree_of(world);
+    const bool tree = d_octree != nullptr;
+    std::string name;
+    if (world->precision == RT_PRECISION_FP16) name = render_kernel_name_h(tree, mode);
+    else {
+        DevAccel acc{};
+        if (tree) { acc = d_octree->accel.p; acc.enabled = acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
+        name = render_kernel_name(tree, mode, acc);
+    }
+    if ((int)name.size() + 1 > cap) return RT_EINVAL;
+    memcpy(out, name.c_str(), name.size() + 1);
+    return 0;
 }
 
 int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream) {
@@ -496,15 +668,11 @@ int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int n
 int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float* d_rays, int64_t n, rt_hit_record* d_out, void* stream) {
     if (!world || !d_rays || !d_out || n < 0) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
-    if (!d_octree) d_octree = list_tree_of(world);
-    int rc = rt_world_upload(const_cast<rt_world*>(world));
-    if (!rc && d_octree) rc = rt_octree_upload(const_cast<rt_octree*>(d_octree));
+    const int rc = ensure_on_device(world, d_octree);
     if (rc) return rc;
-    DevTree T;
-    if (d_octree) { T = d_octree->dev; T.acc.enabled = d_octree->dev.acc.enabled && d_octree->traversal == RT_TRAVERSAL_FAST; }
-    else memset(&T, 0, sizeof(T));
-    if (world->precision == RT_PRECISION_FP16) return (int)launch_trace_h(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
-    return (int)launch_trace(world->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
+    const DevTree T = tree_args(d_octree);
+    if (world->precision == RT_PRECISION_FP16) return (int)launch_trace_h(world->z->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
+    return (int)launch_trace(world->z->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
 
 #ifdef RT_STATS
@@ -519,39 +687,40 @@ static float channel(const void* fb, size_t k, int precision) {
     return ((const float*)fb)[k];
 }
 
+// output_to_stream (main.cu:321-333) into a string: the one formatter behind rt_format_ppm and rt_write_ppm
+static void ppm_text(int nx, int ny, const void* fb, int precision, std::string& s) {
+    s.reserve((size_t)nx * ny * 12 + 32);
+    s += "P3\n"; s += std::to_string(nx); s += ' '; s += std::to_string(ny); s += "\n255\n";
+    char line[48];
+    for (int j = ny - 1; j >= 0; j--) {
+        for (int i = 0; i < nx; i++) {
+            const size_t pixel_index = (size_t)j * nx + i;
+            const int ir = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 0, precision));
+            const int ig = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 1, precision));
+            const int ib = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 2, precision));
+            const int len = snprintf(line, sizeof(line), "%d %d %d\n", ir, ig, ib);
+            s.append(line, (size_t)len);
+        }
+    }
+}
+
 int64_t rt_format_ppm(int nx, int ny, const void* fb, int precision, char* out, int64_t cap) {
     if (nx <= 0 || ny <= 0 || !fb) return RT_EINVAL;
     std::string s;
-    try {
-        s.reserve((size_t)nx * ny * 12 + 32);
-        s += "P3\n"; s += std::to_string(nx); s += ' '; s += std::to_string(ny); s += "\n255\n";
-        char line[48];
-        for (int j = ny - 1; j >= 0; j--) {
-            for (int i = 0; i < nx; i++) {
-                const size_t pixel_index = (size_t)j * nx + i;
-                const int ir = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 0, precision));
-                const int ig = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 1, precision));
-                const int ib = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 2, precision));
-                const int len = snprintf(line, sizeof(line), "%d %d %d\n", ir, ig, ib);
-                s.append(line, (size_t)len);
-            }
-        }
-    } catch (const std::bad_alloc&) { return RT_ENOMEM; }
+    try { ppm_text(nx, ny, fb, precision, s); } catch (const std::bad_alloc&) { return RT_ENOMEM; }
     if (out && (int64_t)s.size() <= cap) memcpy(out, s.data(), s.size());
     return (int64_t)s.size();
 }
 
 int rt_write_ppm(const char* path, int nx, int ny, const void* fb, int precision) {
-    const int64_t need = rt_format_ppm(nx, ny, fb, precision, nullptr, 0);
-    if (need < 0) return (int)need;
-    std::string buf;
-    try { buf.resize((size_t)need); } catch (const std::bad_alloc&) { return RT_ENOMEM; }
-    rt_format_ppm(nx, ny, fb, precision, &buf[0], need);
+    if (nx <= 0 || ny <= 0 || !fb) return RT_EINVAL;
+    std::string s;                                            // formatted once, written straight from the string
+    try { ppm_text(nx, ny, fb, precision, s); } catch (const std::bad_alloc&) { return RT_ENOMEM; }
     FILE* f = path ? fopen(path, "wb") : stdout;
     if (!f) return RT_EIO;
-    const size_t w = fwrite(buf.data(), 1, buf.size(), f);
-    if (path) fclose(f); else fflush(f);
-    return w == buf.size() ? 0 : RT_EIO;
+    const size_t w = fwrite(s.data(), 1, s.size(), f);
+    if (path) { if (fclose(f) != 0) return RT_EIO; } else fflush(f);
+    return w == s.size() ? 0 : RT_EIO;
 }
 
 int rt_write_image(const char* path, int nx, int ny, const void* fb, int precision, int format) {

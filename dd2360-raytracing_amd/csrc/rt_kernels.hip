@@ -1673,16 +1673,30 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     return hipGetLastError();
 }
 
+// Which k_render instantiation a call launches — the ONE place that decides (launch_render and rt_render_kernel_name):
+// 0 = k_render<false,MODE,1> (list scan), 1 = k_render<true,MODE,1> (plain), 4 = k_render<true,0,4> (sparse grids: the
+// variant whose cooperative walk serves up to four rays side by side, rt_accel.h: coop_groups)
+static int render_variant(bool tree, int mode, const DevAccel& acc) {
+    if (!tree) return 0;
+    return (mode == 0 && acc.enabled && acc.coop_groups >= 4) ? 4 : 1;
+}
+const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
+    switch (render_variant(tree, mode, acc)) {
+        case 0: return mode == 0 ? "k_render<false,0,1>" : "k_render<false,1,1>";
+        case 4: return "k_render<true,0,4>";
+        default: return mode == 0 ? "k_render<true,0,1>" : "k_render<true,1,1>";
+    }
+}
+
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
-    if (!tree) return launch_render_list(A, mode, st);
+    const int variant = render_variant(tree, mode, A.tree.acc);
+    if (variant == 0) return launch_render_list(A, mode, st);
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
     const size_t lds = (size_t)A.tree.n_nodes * sizeof(DevNode);
-    // sparse grids: the variant whose cooperative walk serves up to four rays side by side (rt_accel.h: coop_groups)
-    const bool groups = mode == 0 && A.tree.acc.enabled && A.tree.acc.coop_groups >= 4;
-    const unsigned cap = groups ? resident_blocks(k_render<true, 0, 4>, lds) : mode == 0 ? resident_blocks(k_render<true, 0, 1>, lds) : resident_blocks(k_render<true, 1, 1>, lds);
+    const unsigned cap = variant == 4 ? resident_blocks(k_render<true, 0, 4>, lds) : mode == 0 ? resident_blocks(k_render<true, 0, 1>, lds) : resident_blocks(k_render<true, 1, 1>, lds);
     const unsigned blocks = need < cap ? need : cap;
-    if (groups) hipLaunchKernelGGL((k_render<true, 0, 4>), dim3(blocks), dim3(256), lds, st, A);
+    if (variant == 4) hipLaunchKernelGGL((k_render<true, 0, 4>), dim3(blocks), dim3(256), lds, st, A);
     else if (mode == 0) hipLaunchKernelGGL((k_render<true, 0, 1>), dim3(blocks), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_render<true, 1, 1>), dim3(blocks), dim3(256), lds, st, A);
     return hipGetLastError();

@@ -418,6 +418,10 @@ static unsigned resident_blocks_h(const void* kernel, size_t lds) {
     return (unsigned)(cus * per_cu);
 }
 
+const char* render_kernel_name_h(bool tree, int mode) {
+    return tree ? (mode == 0 ? "k_render_h<true,0>" : "k_render_h<true,1>") : (mode == 0 ? "k_render_h<false,0>" : "k_render_h<false,1>");
+}
+
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);

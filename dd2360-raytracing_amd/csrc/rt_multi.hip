@@ -1,0 +1,223 @@
+// rt_multi.hip — one frame over the GPUs of a node: rt_multi_render (include/rt_amd.h).
+//
+// No reference counterpart (the reference is single-GPU); the launch surface it extends is main.cu:422-427.  One process per
+// GPU.  The frame's 8x8 tiles (the reference's block shape, main.cu:351-352) are dealt round-robin, tile t -> rank t % nranks,
+// so cheap sky tiles and expensive ground tiles mix on every GPU; pixels are independent (the per-pixel RNG is keyed by the
+// absolute pixel_index, main.cu:93), so every split gives the bits of the single-GPU frame.  Each rank renders its tiles
+// into a compact tile-major buffer (rt_partition) and ONE exchange brings the buffers to the root: with RCCL a single
+// ncclGroupStart / ncclRecv x (nranks-1) | ncclSend / ncclGroupEnd straight out of the render buffer and straight into the
+// root's staging slots (the root renders into its own slot: no copy anywhere), on the caller's stream; then rt_assemble
+// restores the row-major frame.  Payload at 3840x2160: 99.5 MB in all, 12.4 MB per peer, each on its own xGMI link.
+//
+// RCCL is bound at run time (dlopen "librccl.so.1": a process that already carries an RCCL — PyTorch — shares it; a
+// single-GPU user of librt_amd.so needs none).  rt_multi_init_custom takes the exchange as a callback instead (MPI, gloo, a
+// test harness): same partition, same buffers, same assemble.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <new>
+#include <cstring>
+#include "../../include/rt_amd.h"
+
+namespace {
+
+// the few RCCL entry points used, with the types of /opt/rocm/include/rccl/rccl.h (ncclResult_t and the enums are ints)
+struct NcclId { char internal[128]; };
+typedef void* NcclComm;
+enum { kNcclFloat16 = 6, kNcclFloat32 = 7 };        // ncclFloat16 / ncclFloat32 of rccl.h
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl R;
+    if (R.lib) return R;
+    R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.lib) return R;
+    R.GetUniqueId = (int (*)(NcclId*))dlsym(R.lib, "ncclGetUniqueId");
+    R.CommInitRank = (int (*)(NcclComm*, int, NcclId, int))dlsym(R.lib, "ncclCommInitRank");
+    R.CommDestroy = (int (*)(NcclComm))dlsym(R.lib, "ncclCommDestroy");
+    R.GroupStart = (int (*)())dlsym(R.lib, "ncclGroupStart");
+    R.GroupEnd = (int (*)())dlsym(R.lib, "ncclGroupEnd");
+    R.Send = (int (*)(const void*, size_t, int, int, NcclComm, hipStream_t))dlsym(R.lib, "ncclSend");
+    R.Recv = (int (*)(void*, size_t, int, int, NcclComm, hipStream_t))dlsym(R.lib, "ncclRecv");
+    R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv;
+    return R;
+}
+#define RT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define RT_NCCL(expr) do { if ((expr) != 0) return RT_ECOMM; } while (0)
+
+}  // namespace
+
+struct rt_multi {
+    int rank = 0, nranks = 1;
+    NcclComm comm = nullptr;
+    rt_gather_fn gather = nullptr; void* user = nullptr;
+    rt_render_ctx* ctx = nullptr;
+    // this rank's RNG states (compact, tile-major), its frame part when it is not the root, the root's staging slots
+    void* d_rand = nullptr; size_t rand_bytes = 0;
+    void* d_local = nullptr; size_t local_bytes = 0;
+    void* d_parts = nullptr; size_t parts_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+};
+
+static int grow(void** p, size_t* have, size_t need) {
+    if (*have >= need) return 0;
+    if (*p) { RT_TRY(hipFree(*p)); *p = nullptr; *have = 0; }
+    RT_TRY(hipMalloc(p, need));
+    *have = need;
+    return 0;
+}
+
+static int multi_new(rt_multi** out, int rank, int nranks) {
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks) return RT_EINVAL;
+    *out = nullptr;
+    rt_multi* M = new (std::nothrow) rt_multi();
+    if (!M) return RT_ENOMEM;
+    M->rank = rank; M->nranks = nranks;
+    int rc = rt_render_ctx_create(&M->ctx);
+    if (!rc) { hipError_t e = hipEventCreate(&M->ev0); if (e == hipSuccess) e = hipEventCreate(&M->ev1); rc = (int)e; }
+    if (rc) { rt_multi_destroy(M); return rc; }
+    *out = M;
+    return 0;
+}
+
+extern "C" {
+
+int rt_multi_unique_id(void* id_out) {
+    if (!id_out) return RT_EINVAL;
+    Rccl& R = rccl();
+    if (!R.ok) return RT_ENOTSUP;
+    NcclId id;
+    RT_NCCL(R.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int rt_multi_init(rt_multi** out, int rank, int nranks, const void* unique_id) {
+    if (!unique_id) return RT_EINVAL;
+    Rccl& R = rccl();
+    if (!R.ok) return RT_ENOTSUP;
+    int rc = multi_new(out, rank, nranks);
+    if (rc) return rc;
+    NcclId id;
+    memcpy(&id, unique_id, sizeof(id));
+    if (R.CommInitRank(&(*out)->comm, nranks, id, rank) != 0) { rt_multi_destroy(*out); *out = nullptr; return RT_ECOMM; }
+    return 0;
+}
+
+int rt_multi_init_custom(rt_multi** out, int rank, int nranks, rt_gather_fn gather, void* user) {
+    if (!gather) return RT_EINVAL;
+    const int rc = multi_new(out, rank, nranks);
+    if (rc) return rc;
+    (*out)->gather = gather; (*out)->user = user;
+    return 0;
+}
+
+int rt_multi_destroy(rt_multi* M) {
+    if (!M) return 0;
+    int rc = 0;
+    if (M->comm && rccl().ok && rccl().CommDestroy(M->comm) != 0) rc = RT_ECOMM;
+    void* bufs[3] = {M->d_rand, M->d_local, M->d_parts};
+    for (void* b : bufs) if (b) { const hipError_t e = hipFree(b); if (e != hipSuccess && !rc) rc = (int)e; }
+    if (M->ev0) (void)hipEventDestroy(M->ev0);
+    if (M->ev1) (void)hipEventDestroy(M->ev1);
+    const int r2 = rt_render_ctx_destroy(M->ctx); if (!rc) rc = r2;
+    delete M;
+    return rc;
+}
+
+// buffers for frames of this size (rt_multi_render grows them on demand; call this once before timing or graph capture)
+int rt_multi_reserve(rt_multi* M, int max_x, int max_y, int precision, int root) {
+    if (!M || max_x <= 0 || max_y <= 0 || root < 0 || root >= M->nranks) return RT_EINVAL;
+    if (precision != RT_PRECISION_FP32 && precision != RT_PRECISION_FP16) return RT_EINVAL;
+    const size_t px = precision == RT_PRECISION_FP16 ? 6 : 12;
+    const rt_partition mine = {M->rank, M->nranks}, first = {0, M->nranks};
+    const int64_t n_mine = rt_part_pixels(max_x, max_y, mine), per = rt_part_pixels(max_x, max_y, first);
+    int rc = grow(&M->d_rand, &M->rand_bytes, (size_t)(n_mine > 0 ? n_mine : 1) * sizeof(rt_rand_state));
+    if (!rc && M->rank == root) rc = grow(&M->d_parts, &M->parts_bytes, (size_t)per * px * (size_t)M->nranks);
+    if (!rc && M->rank != root) rc = grow(&M->d_local, &M->local_bytes, (size_t)per * px);
+    if (!rc) rc = rt_render_ctx_reserve(M->ctx, max_x, max_y, mine);
+    return rc;
+}
+
+int rt_multi_render(rt_multi* M, void* fb_full, int max_x, int max_y, int ns, const rt_world* world, const rt_octree* d_octree, int precision, int root, void* stream) {
+    if (!M || !world || max_x <= 0 || max_y <= 0 || ns <= 0 || root < 0 || root >= M->nranks) return RT_EINVAL;
+    if (M->rank == root && !fb_full) return RT_EINVAL;
+    int rc = rt_multi_reserve(M, max_x, max_y, precision, root);
+    if (rc) return rc;
+    const hipStream_t st = (hipStream_t)stream;
+    const size_t px = precision == RT_PRECISION_FP16 ? 6 : 12;
+    const rt_partition mine = {M->rank, M->nranks}, first = {0, M->nranks};
+    const int64_t per = rt_part_pixels(max_x, max_y, first);
+    const size_t stride = (size_t)per * px;
+    // the root renders straight into its slot of the staging buffer, the others into their send buffer; a single rank's
+    // "part" is the whole frame in the reference's row-major layout (rt_partition, nparts == 1): straight into fb_full
+    void* local = M->nranks == 1 ? fb_full : M->rank == root ? (void*)((char*)M->d_parts + stride * (size_t)root) : M->d_local;
+    RT_TRY(hipEventRecord(M->ev0, st));
+    if ((rc = rt_render_init(max_x, max_y, (rt_rand_state*)M->d_rand, mine, stream))) return rc;
+    if ((rc = rt_render_on(M->ctx, local, max_x, max_y, ns, world, (rt_rand_state*)M->d_rand, d_octree, mine, stream))) return rc;
+    RT_TRY(hipEventRecord(M->ev1, st));
+    M->timed = true;
+    if (M->nranks > 1) {
+        const size_t mine_bytes = (size_t)rt_part_pixels(max_x, max_y, mine) * px;
+        if (M->gather) {
+            if ((rc = M->gather(M->user, local, mine_bytes, M->rank == root ? M->d_parts : nullptr, stride, root, stream))) return rc > 0 ? RT_ECOMM : rc;
+        } else {
+            Rccl& R = rccl();
+            const int dtype = precision == RT_PRECISION_FP16 ? kNcclFloat16 : kNcclFloat32;
+            RT_NCCL(R.GroupStart());                              // the single framebuffer exchange
+            if (M->rank == root) {
+                for (int r = 0; r < M->nranks; ++r) {
+                    if (r == root) continue;
+                    const rt_partition pr = {r, M->nranks};
+                    const size_t count = (size_t)rt_part_pixels(max_x, max_y, pr) * 3;
+                    if (count && R.Recv((char*)M->d_parts + stride * (size_t)r, count, dtype, r, M->comm, st) != 0) { (void)R.GroupEnd(); return RT_ECOMM; }
+                }
+            } else if (mine_bytes) {
+                if (R.Send(local, mine_bytes / (px / 3), dtype, root, M->comm, st) != 0) { (void)R.GroupEnd(); return RT_ECOMM; }
+            }
+            RT_NCCL(R.GroupEnd());
+        }
+    }
+    if (M->rank == root && M->nranks > 1) rc = rt_assemble(fb_full, M->d_parts, max_x, max_y, M->nranks, precision, stream);
+    return rc;
+}
+
+// device time of this rank's own share of the last rt_multi_render (render_init + render, before the exchange), and of
+// its render kernel alone; synchronises with the recorded events
+int rt_multi_last_render_ms(rt_multi* M, float* call_ms, float* kernel_ms) {
+    if (!M || !M->timed) return RT_EINVAL;
+    RT_TRY(hipEventSynchronize(M->ev1));
+    float ms = 0.f;
+    RT_TRY(hipEventElapsedTime(&ms, M->ev0, M->ev1));
+    if (call_ms) *call_ms = ms;
+    if (kernel_ms) {
+        float k[64]; int n = 0;
+        const int rc = rt_render_ctx_times(M->ctx, k, 64, &n);
+        if (rc) return rc;
+        *kernel_ms = n > 0 ? k[n - 1] : 0.f;
+    }
+    return 0;
+}
+
+// One ncclSend + ncclRecv of `bytes` bytes from this rank to itself inside a group, on the caller's stream: checks that
+// the RCCL bound at run time moves device memory in this process (what a one-GPU box can check of the RCCL path).
+int rt_multi_selftest(rt_multi* M, const void* d_src, void* d_dst, size_t bytes, void* stream) {
+    if (!M || !M->comm || !d_src || !d_dst) return RT_EINVAL;
+    Rccl& R = rccl();
+    RT_NCCL(R.GroupStart());
+    const int a = R.Send(d_src, bytes, 0 /* ncclInt8 */, M->rank, M->comm, (hipStream_t)stream);
+    const int b = R.Recv(d_dst, bytes, 0, M->rank, M->comm, (hipStream_t)stream);
+    RT_NCCL(R.GroupEnd());
+    return (a || b) ? RT_ECOMM : 0;
+}
+
+}  // extern "C"

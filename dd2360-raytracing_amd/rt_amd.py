@@ -67,6 +67,21 @@ SYMBOLS = {
     "rt_render": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
     "rt_render_progressive": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
     "rt_world_render_times": (_i, [_vp, _vp, _i, _vp]),
+    "rt_render_ctx_create": (_i, [_vp]),
+    "rt_render_ctx_reserve": (_i, [_vp, _i, _i, Partition]),
+    "rt_render_ctx_destroy": (_i, [_vp]),
+    "rt_render_on": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
+    "rt_render_progressive_on": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
+    "rt_render_ctx_times": (_i, [_vp, _vp, _i, _vp]),
+    "rt_render_kernel_name": (_i, [_vp, _vp, _i, _vp, _i]),
+    "rt_multi_unique_id": (_i, [_vp]),
+    "rt_multi_init": (_i, [_vp, _i, _i, _vp]),
+    "rt_multi_init_custom": (_i, [_vp, _i, _i, _vp, _vp]),
+    "rt_multi_destroy": (_i, [_vp]),
+    "rt_multi_reserve": (_i, [_vp, _i, _i, _i, _i]),
+    "rt_multi_render": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "rt_multi_last_render_ms": (_i, [_vp, _vp, _vp]),
+    "rt_multi_selftest": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "rt_assemble": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rt_trace_rays": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _i, _i, _vp, _i]),
@@ -122,6 +137,101 @@ def _dev(t):
 def _stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def render_kernel_name(world, octree=None, mode=0):
+    """the kernel rt_render (mode 0) / rt_render_progressive (mode 1) launches for this world and tree (the library's own rule)"""
+    buf = C.create_string_buffer(64)
+    check(lib().rt_render_kernel_name(world.h, octree.h if octree is not None else None, mode, buf, 64), "rt_render_kernel_name")
+    return buf.value.decode()
+
+
+class RenderCtx:
+    """rt_render_ctx: per-launch state for frames rendered concurrently on one GPU (one context per stream)"""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().rt_render_ctx_create(C.byref(h)), "rt_render_ctx_create")
+        self.h = h
+
+    def reserve(self, max_x, max_y, part=None):
+        check(lib().rt_render_ctx_reserve(self.h, max_x, max_y, part or WHOLE), "rt_render_ctx_reserve")
+        return self
+
+    def render(self, fb, max_x, max_y, ns, world, d_rand_state, octree=None, part=None, stream=None):
+        check(lib().rt_render_on(self.h, _dev(fb), max_x, max_y, ns, world.h, _dev(d_rand_state), octree.h if octree is not None else None,
+                                 part or WHOLE, C.c_void_p(stream) if stream is not None else _stream()), "rt_render_on")
+
+    def times(self):
+        out = np.zeros(64, np.float32)
+        n = C.c_int(0)
+        check(lib().rt_render_ctx_times(self.h, _np(out), 64, C.byref(n)), "rt_render_ctx_times")
+        return out[: n.value].tolist()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_render_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+MULTI_ID_BYTES = 128
+
+
+def multi_unique_id():
+    """rank 0: the RCCL unique id (bytes) to hand to the other ranks"""
+    buf = C.create_string_buffer(MULTI_ID_BYTES)
+    check(lib().rt_multi_unique_id(buf), "rt_multi_unique_id")
+    return buf.raw
+
+
+class Multi:
+    """rt_multi: tile split over the ranks of a node + the single framebuffer exchange + rt_assemble on the root.
+    unique_id (bytes) selects RCCL; gather (a Python callable with the rt_gather_fn arguments) a custom exchange."""
+
+    def __init__(self, rank, nranks, unique_id=None, gather=None):
+        h = C.c_void_p()
+        if gather is not None:
+            self._cb = GATHER_FN(gather)                          # keep the thunk alive
+            check(lib().rt_multi_init_custom(C.byref(h), rank, nranks, C.cast(self._cb, C.c_void_p), None), "rt_multi_init_custom")
+        else:
+            assert unique_id is not None and len(unique_id) == MULTI_ID_BYTES
+            self._id = C.create_string_buffer(unique_id, MULTI_ID_BYTES)
+            check(lib().rt_multi_init(C.byref(h), rank, nranks, self._id), "rt_multi_init")
+        self.h, self.rank, self.nranks = h, rank, nranks
+
+    def reserve(self, max_x, max_y, precision=FP32, root=0):
+        check(lib().rt_multi_reserve(self.h, max_x, max_y, precision, root), "rt_multi_reserve")
+        return self
+
+    def render(self, fb_full, max_x, max_y, ns, world, octree=None, root=0):
+        check(lib().rt_multi_render(self.h, _dev(fb_full) if fb_full is not None else None, max_x, max_y, ns, world.h,
+                                    octree.h if octree is not None else None, world.precision, root, _stream()), "rt_multi_render")
+
+    def last_render_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        check(lib().rt_multi_last_render_ms(self.h, C.byref(a), C.byref(b)), "rt_multi_last_render_ms")
+        return a.value, b.value
+
+    def selftest(self, d_src, d_dst, nbytes):
+        check(lib().rt_multi_selftest(self.h, _dev(d_src), _dev(d_dst), nbytes, _stream()), "rt_multi_selftest")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_check():
@@ -299,9 +409,9 @@ def write_image(path, fb_host, nx, ny, precision=FP32, fmt=IMAGE_P6):
 
 def format_ppm(fb_host, nx, ny, precision=FP32):
     fb_host = np.ascontiguousarray(fb_host)
-    n = lib().rt_format_ppm(nx, ny, _np(fb_host), precision, None, 0)
-    if n < 0:
+    cap = nx * ny * 36 + 64                                      # three ints of <= 11 characters per pixel: formatted once
+    buf = C.create_string_buffer(cap)
+    n = lib().rt_format_ppm(nx, ny, _np(fb_host), precision, buf, cap)
+    if n < 0 or n > cap:
         raise RtError("rt_format_ppm failed: %d" % n)
-    buf = C.create_string_buffer(n)
-    lib().rt_format_ppm(nx, ny, _np(fb_host), precision, buf, n)
     return buf.raw[:n]

@@ -21,13 +21,14 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define RT_EINVAL (-1)
 #define RT_ENOMEM (-2)
 #define RT_EIO (-3)
 #define RT_ENOTSUP (-4)
+#define RT_ECOMM (-5)   /* the multi-GPU exchange failed (RCCL error, or the custom gather returned non-zero) */
 
 /* real_t selection — precision_types.h:8 (USE_FP16) */
 #define RT_PRECISION_FP32 0
@@ -82,6 +83,8 @@ typedef struct rt_hit_record {
     int32_t sphere;
 } rt_hit_record;
 
+typedef struct rt_render_ctx rt_render_ctx; /* per-launch state of rt_render: work counters, scheduling workspace, timing events */
+typedef struct rt_multi rt_multi;   /* one frame over the GPUs of a node (one process per GPU) */
 typedef struct rt_world rt_world;   /* device-resident scene: what d_list / d_world / d_camera reach (main.cu:393-398) */
 typedef struct rt_octree rt_octree; /* Octree (acceleration_structure.h:57-62): host reference layout + device traversal copy */
 
@@ -167,6 +170,26 @@ int rt_render(void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_
 int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, const rt_world* world,
                           rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream);
 
+/* Render contexts.  rt_render / rt_render_progressive keep their per-launch state (work counters, the scheduling workspace of
+ * the pilot pass, timing events) in a context owned by the world handle.  Launches that share a context are ordered by the
+ * library (the next call's stream waits for the previous render kernel), so calls on one world from several streams are safe
+ * but run one after the other; frames that should overlap on one GPU — two partitions of a frame on two streams — take a
+ * context each and go through the *_on entry points.  A context first used inside a hipGraph capture must have been
+ * prepared before (rt_render_ctx_reserve, or one uncaptured call of the same frame size); timing events are not recorded
+ * during a capture. */
+int rt_render_ctx_create(rt_render_ctx** out);
+int rt_render_ctx_reserve(rt_render_ctx* ctx, int max_x, int max_y, rt_partition part);   /* workspace for frames of this size, now */
+int rt_render_ctx_destroy(rt_render_ctx* ctx);
+int rt_render_on(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state,
+                 const rt_octree* d_octree, rt_partition part, void* stream);
+int rt_render_progressive_on(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int current_sample, const rt_world* world,
+                             rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream);
+int rt_render_ctx_times(rt_render_ctx* ctx, float* ms_out, int max, int* count);           /* as rt_world_render_times */
+
+/* Name of the kernel rt_render (mode 0) / rt_render_progressive (mode 1) launches for this world and tree (d_octree NULL =
+ * the hitable_list path), as rocprofv3 shows it without the namespace: "k_render<true,0,4>", "k_render_h<true,0>", ... */
+int rt_render_kernel_name(const rt_world* world, const rt_octree* d_octree, int mode, char* out, int cap);
+
 /* Device time of the dominant kernel (k_render / k_render_h) of the most recent rt_render / rt_render_progressive calls on
  * this world: HIP events recorded on the launch stream directly around that kernel (the scheduling pre-pass of rt_render
  * is outside).  Copies up to `max` durations (milliseconds, oldest first, at most the last 64 launches) into ms_out,
@@ -176,6 +199,36 @@ int rt_world_render_times(rt_world* world, float* ms_out, int max, int* count);
 /* Reassemble a full row-major frame from nparts tile-major part buffers laid out back to back, each padded to
  * rt_part_pixels(max_x,max_y,{0,nparts}) elements (the layout an all-gather of the parts produces). */
 int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream);
+
+/* ---- multi-GPU: one frame over the GPUs of one node, one process per GPU -------------------------------------------------
+ * No reference counterpart (the reference is single-GPU, launch surface main.cu:422-427).  Rank r of nranks renders the tiles
+ * t with t % nranks == r (rt_partition{r, nranks}) of every frame; ONE exchange brings the compact part buffers to the root
+ * (RCCL over xGMI: one ncclGroupStart / ncclRecv x (nranks-1) | ncclSend / ncclGroupEnd, straight from the render buffer
+ * into the root's staging slots, on the caller's stream), where rt_assemble writes the row-major frame into fb_full.
+ * rt_multi_unique_id: rank 0 creates the 128-byte RCCL id and hands it to the other ranks by any means (a file, MPI,
+ * torch.distributed over gloo); rt_multi_init: ncclCommInitRank on the calling process's current device.  RCCL is bound at
+ * run time (dlopen): RT_ENOTSUP when it is absent. */
+#define RT_MULTI_ID_BYTES 128
+int rt_multi_unique_id(void* id_out /* [RT_MULTI_ID_BYTES] */);
+int rt_multi_init(rt_multi** out, int rank, int nranks, const void* unique_id);
+/* The same with a caller-supplied exchange (MPI, gloo, a test harness) instead of RCCL.  Called on every rank after its part
+ * is rendered (enqueued on `stream`): rank r's send_bytes at d_send must arrive at d_parts + r * part_stride_bytes on the
+ * root before work enqueued on the root's stream afterwards runs.  The root's own part is in place already (its d_send IS its
+ * slot); d_parts is NULL on the other ranks.  Device pointers.  Return 0 on success. */
+typedef int (*rt_gather_fn)(void* user, const void* d_send, size_t send_bytes, void* d_parts, size_t part_stride_bytes, int root, void* stream);
+int rt_multi_init_custom(rt_multi** out, int rank, int nranks, rt_gather_fn gather, void* user);
+int rt_multi_destroy(rt_multi* m);
+/* buffers for frames of this size now (otherwise the first rt_multi_render of a larger frame allocates) */
+int rt_multi_reserve(rt_multi* m, int max_x, int max_y, int precision, int root);
+/* render_init + render of this rank's tiles, the exchange, and on the root the assembled frame in fb_full (device buffer of
+ * max_x*max_y vec3, reference layout; ignored on the other ranks).  precision must be the world's.  Asynchronous on `stream`. */
+int rt_multi_render(rt_multi* m, void* fb_full, int max_x, int max_y, int ns, const rt_world* world, const rt_octree* d_octree,
+                    int precision, int root, void* stream);
+/* device time of this rank's own share of the last rt_multi_render: render_init + render (call_ms) and the render kernel
+ * alone (kernel_ms) — the ranks' values side by side show the load balance of the tile split.  Synchronises. */
+int rt_multi_last_render_ms(rt_multi* m, float* call_ms, float* kernel_ms);
+/* RCCL contexts only: one ncclSend + ncclRecv of `bytes` bytes from this rank to itself inside one group on `stream` */
+int rt_multi_selftest(rt_multi* m, const void* d_src, void* d_dst, size_t bytes, void* stream);
 
 /* hitTree (acceleration_structure.h:319-342) / hitable_list::hit (hitable_list.h:16-31) for a batch of rays:
  * d_rays = n x 6 floats (origin, direction) on the device, d_out = n records on the device. t in (0.001, FLT_MAX). */

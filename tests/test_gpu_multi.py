@@ -1,0 +1,110 @@
+"""Multi-GPU entry points of the C-ABI on the one GPU of the test box (-m gpu): rt_multi_render with an RCCL communicator of
+one rank, RCCL bound at run time moving device memory (self send/recv), N ranks as N fresh child processes on GPU 0 through
+the custom-gather form (RCCL refuses two ranks on one device), and render contexts on concurrent streams."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def whole_frame(rt, torch, W, O, nx, ny, ns, precision=None):
+    precision = rt.FP32 if precision is None else precision
+    st = rt.alloc_rand_state(nx, ny)
+    fb = rt.alloc_fb(nx, ny, precision=precision)
+    rt.render_init(nx, ny, st)
+    rt.render(fb, nx, ny, ns, W, st, O)
+    torch.cuda.synchronize()
+    return fb, st
+
+
+def test_multi_render_one_rank_over_rccl(rt, cuda):
+    """rt_multi_unique_id + rt_multi_init (ncclCommInitRank, RCCL dlopen'ed) with one rank: rt_multi_render equals rt_render, and
+    a grouped ncclSend/ncclRecv to self moves device bytes on the caller's stream."""
+    torch = cuda
+    nx, ny, ns, n, spl = 200, 120, 8, 500, 30
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, spl)
+    M = rt.Multi(0, 1, unique_id=rt.multi_unique_id())
+    full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda")
+    M.render(full, nx, ny, ns, W, O)
+    torch.cuda.synchronize()
+    fb, _ = whole_frame(rt, torch, W, O, nx, ny, ns)
+    assert torch.equal(full.view(torch.int32), fb.view(torch.int32))
+    call_ms, kernel_ms = M.last_render_ms()
+    assert 0 < kernel_ms <= call_ms
+    src = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+    dst = torch.zeros_like(src)
+    M.selftest(src, dst, src.numel() * 4)
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    M.close()
+
+
+@pytest.mark.parametrize("world,nx,ny,ns,n,spl,fp16", [
+    (2, 400, 232, 16, 10000, 32, 0),         # octree, long-chain classification on
+    (3, 203, 117, 4, 500, 0, 0),             # ragged frame, three ranks, hitable_list path
+    (2, 200, 120, 4, 500, 30, 1),            # USE_FP16
+])
+def test_multi_render_child_processes_on_one_gpu(rt, cuda, world, nx, ny, ns, n, spl, fp16):
+    """N fresh child processes, one rank each, all on GPU 0: the real rt_multi_render (partition, render, staging slots,
+    rt_assemble) with a gloo exchange; rank 0 checks the assembled frame against a single-process render bit for bit."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(ROOT, "tests", "multi_worker.py")
+    args = [str(v) for v in (world, port, nx, ny, ns, n, spl, fp16)]
+    procs = [subprocess.Popen([sys.executable, script, str(r)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            outs.append((p.returncode, o.decode(), e.decode()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rc, o, e in outs:
+        assert rc == 0, (rc, o[-2000:], e[-2000:])
+    assert "EQUALS" in outs[0][1]
+
+
+def test_render_calls_on_two_streams(rt, cuda):
+    """two partitions of one frame rendered on two streams.  Through the world's own context the calls are
+    ordered by the library; with a context each they overlap.  Both ways every part equals the part rendered alone."""
+    torch = cuda
+    nx, ny, ns, n, spl = 400, 232, 16, 10000, 32
+    W = rt.World(n, nx, ny).upload()
+    O = rt.Octree(W, spl).upload()
+    parts = [rt.Partition(p, 2) for p in range(2)]
+    ref = []
+    for part in parts:
+        st = rt.alloc_rand_state(nx, ny, part); fb = rt.alloc_fb(nx, ny, part)
+        rt.render_init(nx, ny, st, part); rt.render(fb, nx, ny, ns, W, st, O, part)
+        torch.cuda.synchronize()
+        ref.append((fb.clone(), st.clone()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for mode in ("shared", "own"):
+        ctxs = [rt.RenderCtx().reserve(nx, ny, part) for part in parts] if mode == "own" else [None, None]
+        bufs = []
+        for _ in range(3):                                           # a few rounds: races do not show every time
+            bufs = [(rt.alloc_fb(nx, ny, part), rt.alloc_rand_state(nx, ny, part)) for part in parts]
+            torch.cuda.synchronize()
+            for part, s, ctx, (fb, st) in zip(parts, streams, ctxs, bufs):   # both parts in flight before either is waited for
+                with torch.cuda.stream(s):
+                    rt.render_init(nx, ny, st, part)
+                    if ctx is None:
+                        rt.render(fb, nx, ny, ns, W, st, O, part)
+                    else:
+                        ctx.render(fb, nx, ny, ns, W, st, O, part)
+            torch.cuda.synchronize()
+            for (fb, st), (rfb, rst) in zip(bufs, ref):
+                assert torch.equal(fb.view(torch.int32), rfb.view(torch.int32)) and torch.equal(st, rst), mode
+        if mode == "own":
+            assert all(len(c.times()) == 3 for c in ctxs)
