@@ -168,6 +168,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # test-only switch (tools/rehearse_2rank.sh): all ranks on GPU 0 and the exchange through rt_multi's custom-gather form
+    # over gloo (RCCL refuses two ranks on one device), so the whole N>1 flow can be rehearsed on a one-GPU box; the driver's
+    # runs never set it
+    same_gpu = os.environ.get("RT_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     rc, _ = rt.device_check()
     if rc != 0:
@@ -190,9 +196,13 @@ def main():
     kernel_name = rt.render_kernel_name(W, O, 0)                   # the library's own selection, as rocprofv3 names it
     M = None
     if world > 1:
-        ids = [rt.multi_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        M = rt.Multi(rank, world, unique_id=ids[0]).reserve(nx, ny, precision, 0)
+        if same_gpu:
+            from multi_worker import make_gloo_gather
+            M = rt.Multi(rank, world, gather=make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if cfg.get("fp16") else 12)).reserve(nx, ny, precision, 0)
+        else:
+            ids = [rt.multi_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            M = rt.Multi(rank, world, unique_id=ids[0]).reserve(nx, ny, precision, 0)
         full = torch.zeros(nx * ny * 3, dtype=torch.float16 if cfg.get("fp16") else torch.float32, device="cuda") if rank == 0 else None
     else:
         st = rt.alloc_rand_state(nx, ny)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <limits>
+#include <algorithm>
 #include "rt_device.h"
 #include "../host/rt_scene.hpp"
 #include "rt_accel.h"
@@ -24,6 +25,9 @@ hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const fl
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc);
 const char* render_kernel_name_h(bool tree, int mode);
+#ifdef RT_H16_STATS
+hipError_t read_h16_stats(unsigned long long* out, int reset);
+#endif
 #ifdef RT_STATS
 hipError_t read_stats(unsigned long long* out, int reset);
 hipError_t read_wave_dbg(unsigned long long* out);
@@ -415,14 +419,62 @@ static int octree_upload(const rt_octree* O) {
     if (Z.uploaded) return 0;
     int rc;
     if (O->precision == RT_PRECISION_FP16) {
-        // binary16 trees: the bucket entries as four halves (cx, cy, cz, r^2) in 8 bytes — the values are binary16 numbers
-        // already, this saves the fp16 scan four conversions and half the bytes per sphere test (rt_kernels_fp16.hip)
-        std::vector<uint2> packed(O->h_ent_hot.size());
-        for (size_t k = 0; k < packed.size(); ++k) {
-            const float4 v = O->h_ent_hot[k];
-            packed[k] = make_uint2((uint32_t)half_t(v.x).bits | ((uint32_t)half_t(v.y).bits << 16), (uint32_t)half_t(v.z).bits | ((uint32_t)half_t(v.w).bits << 16));
+        // binary16 trees (rt_kernels_fp16.hip tests two spheres per packed instruction): each node's entries as PAIRS,
+        // 16 bytes a pair — (cx_A | cx_B << 16), (cy..), (cz..), (r^2..) — an odd count padded with a NaN sphere (its
+        // discriminant is never > 0); the node's first/count become pair indices, the entry -> sphere table follows the pairs.
+        // The values are binary16 numbers already (every float of an FP16 world holds an exact binary16 image).
+        std::vector<uint4> pairs; std::vector<int32_t> pid; std::vector<DevNode> hn(O->h_nodes);
+        auto hb = [](float v) { return (uint32_t)half_t(v).bits; };
+        for (DevNode& d : hn) {
+            const int first = d.first, cnt = d.count;
+            d.first = (int32_t)pairs.size();
+            for (int e = 0; e < cnt; e += 2) {
+                const float4 A4 = O->h_ent_hot[(size_t)first + e];
+                const bool two = e + 1 < cnt;
+                const uint32_t nanb = 0x7e00u;
+                const float4 B4 = two ? O->h_ent_hot[(size_t)first + e + 1] : A4;
+                pairs.push_back(make_uint4(hb(A4.x) | ((two ? hb(B4.x) : nanb) << 16), hb(A4.y) | ((two ? hb(B4.y) : nanb) << 16),
+                                           hb(A4.z) | ((two ? hb(B4.z) : nanb) << 16), hb(A4.w) | ((two ? hb(B4.w) : nanb) << 16)));
+                pid.push_back(O->h_ent_id[(size_t)first + e]);
+                pid.push_back(two ? O->h_ent_id[(size_t)first + e + 1] : -1);
+            }
+            d.count = (int32_t)pairs.size() - d.first;
         }
-        rc = upload(packed, &Z.d_ent_hot);
+        if (pairs.size() >= (size_t)1 << 24) return RT_ENOTSUP;         // entry index + 1 shares a dword with the owner lane in the candidate queue
+        // plane table: the distinct box coordinates per axis, and per node its six indices into the concatenated table
+        std::vector<float> planes; int np[3] = {0, 0, 0};
+        {
+            std::vector<float> ax[3];
+            for (const DevNode& d : hn) { const float b[6] = {d.lo[0], d.lo[1], d.lo[2], d.hix, d.hiy, d.hiz}; for (int k = 0; k < 3; ++k) { ax[k].push_back(b[k]); ax[k].push_back(b[3 + k]); } }
+            bool ok = true;
+            for (int k = 0; k < 3; ++k) {
+                std::sort(ax[k].begin(), ax[k].end());
+                ax[k].erase(std::unique(ax[k].begin(), ax[k].end()), ax[k].end());
+                for (float v : ax[k]) if (!(v == v)) ok = false;
+            }
+            if (ok && ax[0].size() + ax[1].size() + ax[2].size() <= 30) {
+                int off[3] = {0, (int)ax[0].size(), (int)(ax[0].size() + ax[1].size())};
+                for (int k = 0; k < 3; ++k) { np[k] = (int)ax[k].size(); planes.insert(planes.end(), ax[k].begin(), ax[k].end()); }
+                for (DevNode& d : hn) {
+                    const float b[6] = {d.lo[0], d.hix, d.lo[1], d.hiy, d.lo[2], d.hiz};        // x_low, x_high, y_low, y_high, z_low, z_high
+                    uint32_t w = 0;
+                    for (int q = 0; q < 6; ++q) {
+                        const int k = q / 2;
+                        const int idx = off[k] + (int)(std::lower_bound(ax[k].begin(), ax[k].end(), b[q]) - ax[k].begin());
+                        w |= (uint32_t)idx << (5 * q);
+                    }
+                    d.pad[0] = (int32_t)w;
+                }
+            }
+        }
+        if (planes.empty()) planes.assign(1, 0.f);
+        Z.dev.h16_np[0] = np[0]; Z.dev.h16_np[1] = np[1]; Z.dev.h16_np[2] = np[2];
+        rc = upload(pairs, &Z.d_ent_hot);
+        if (!rc) rc = upload(hn, &Z.d_nodes);
+        if (!rc) rc = upload(pid, &Z.d_ent_id);
+        if (!rc) rc = upload(planes, &Z.d_acc[11]);
+        Z.dev.h16_planes = (const float*)Z.d_acc[11];
+        Z.dev.n_entries = (int32_t)(2 * pairs.size());
     } else rc = upload(O->h_ent_hot, &Z.d_ent_hot);
     const AccelHost& A = O->accel;
     if (rc || (rc = upload(O->h_nodes, &Z.d_nodes)) || (rc = upload(O->h_ent_id, &Z.d_ent_id)) ||
@@ -435,7 +487,8 @@ static int octree_upload(const rt_octree* O) {
         Z.d_nodes = Z.d_ent_hot = Z.d_ent_id = nullptr;
         return rc;
     }
-    Z.dev.n_nodes = O->n_nodes; Z.dev.n_entries = O->n_entries;
+    Z.dev.n_nodes = O->n_nodes;
+    if (O->precision != RT_PRECISION_FP16) Z.dev.n_entries = O->n_entries;      // (binary16: entry slots of the pair layout, set above)
     Z.dev.nodes4 = (const float4*)Z.d_nodes; Z.dev.ent_hot = (const float4*)Z.d_ent_hot; Z.dev.ent_id = (const int32_t*)Z.d_ent_id;
     DevAccel p = A.p;
     p.large_hot = (const float4*)Z.d_acc[0]; p.large_brick = (const float4*)Z.d_acc[1];
@@ -675,6 +728,9 @@ int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float*
     return (int)launch_trace(world->z->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
 
+#ifdef RT_H16_STATS
+int rt_debug_h16(unsigned long long* out8, int reset) { return (int)rt::read_h16_stats(out8, reset); }      // diagnostic variant only
+#endif
 #ifdef RT_STATS
 // diagnostic build only (librt_amd_stats.so): 16 work counters, see rt_kernels.hip
 int rt_debug_stats(unsigned long long* out16, int reset) { return (int)read_stats(out16, reset); }

@@ -67,6 +67,12 @@ struct DevTree {
     const float4* ent_hot;    // [n_entries] (cx, cy, cz, radius*radius) in traversal order
     const int32_t* ent_id;    // [n_entries] index into the world list
     int32_t n_nodes, n_entries;
+    // binary16 trees only (rt_kernels_fp16.hip): the distinct box planes of the tree per axis — the reference's boxes are the
+    // root box halved three times, 9 planes an axis — so a ray divides once per plane, not six times per visited node.
+    // h16_planes = [x planes | y planes | z planes] (h16_np of each; h16_np[0] == 0: no table, the generic slab test);
+    // DevNode::pad[0] holds the node's six plane indices, 5 bits each: x_low, x_high, y_low, y_high, z_low, z_high.
+    const float* h16_planes;
+    int32_t h16_np[3];
     DevAccel acc;
 };
 

@@ -123,57 +123,327 @@ RT_DEV void closest_list(const DevScene& S, const Ray& r, R a, R& closest, int& 
     if (best >= 0) best = S.list_id[best];
 }
 
-// hitTree (acceleration_structure.h:319-342) in two phases per round, so that the 64 rays of a wave do not wait for each
-// other at every level-3 node: (1) walk the tree — the visited set does not depend on the hits (traverseTree prunes by the
-// slab test only) — and note the bucket ranges of up to kRanges visited non-empty nodes per lane in LDS; (2) scan them as ONE
-// flat sequence of sphere tests per lane, in the reference's order (nodes in traversal order, entries in bucket order).
-// Walking and scanning in lock step per node ran at 14 % lane utilisation (every node a barrier for the whole wave).
-constexpr int kRanges = 24;                                   // nodes noted per lane and round (24 x 256 x 2 B of LDS)
-RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const Ray& r, R a, bool live, R& closest, int& best) {
+// ---------------------------------------------------------------------------------------------------- hitTree, binary16
+// hitTree (acceleration_structure.h:319-342) for the 64 rays of a wave, in rounds of three phases:
+//   1  every lane walks the tree — the visited set does not depend on the hits (traverseTree prunes by the slab test only) —
+//      and puts the bucket range of each visited non-empty node into the WAVE's pool of segments (LDS);
+//   2  the pool's sphere tests are dealt out evenly: lane w takes pairs [w*C, (w+1)*C) of the concatenated segments, whoever
+//      the rays' owners are (a ray crossing eight cells and a ray crossing none cost the same to every lane; scanning each
+//      lane's own buckets ran at 20 % lane utilisation, SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU);
+//   3  every owner picks up its ray's result.
+// Why any order gives the reference's record.  What a sphere offers does not depend on closest_so_far: the near root t1 if
+// t1 > t_min, else the far root t2 if t2 > t_min (sphere.h:24-43; t2 >= t1 also in this mixed arithmetic: nb - x <= nb + y for
+// x, y >= 0, division by a > 0 and rounding are monotone), and it is accepted iff it is < closest_so_far.  The sequential scan
+// therefore ends with the smallest offered t, the FIRST visited sphere among equal t.  Bucket entries are stored in the
+// tree's pre-order — the visit order of every ray — so "first visited" = "lowest entry index": the result is the minimum of
+// the 64-bit keys (t bits << 32 | entry index + 1) (t > t_min > 0: binary16 bits order like the values), seeded with
+// (closest_so_far << 32 | 0) — what the ray holds already (the ground sphere, earlier rounds) wins ties like in the scan.
+// Tests run two spheres at a time in packed binary16 (v_pk_add_f16 / v_pk_mul_f16: one rounding per operation, the same bits
+// as the float-and-round form of rt_real.h).  A positive discriminant is rare (3 % of the tests) and expensive (correctly
+// rounded sqrt, two IEEE divisions), so the test loop never evaluates it in place — 8 sub-slots per pass, each with one or two
+// of the 64 lanes interested, cost 4x the packed arithmetic: a branch-free packed filter first drops spheres surely behind the
+// origin (below), what is left goes into a queue of the wave (LDS), and whenever 64 candidates have gathered all 64 lanes
+// take one each: a cheap float filter against the owner's best so far, then the reference's roots, then an LDS atomic min on
+// the owner's key.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+RT_DEV h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
+RT_DEV uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+RT_DEV uint32_t dup16(R r) { return (uint32_t)r.bits | ((uint32_t)r.bits << 16); }
+RT_DEV h2 pk_min(h2 a, h2 b) { return __builtin_elementwise_min(a, b); }       // v_pk_min_f16 (minNum: a NaN operand loses)
+
+#ifndef RT_H16_POOL
+#define RT_H16_POOL 256
+#endif
+constexpr int kPool = RT_H16_POOL;                            // segments per wave and round (a multiple of 64)
+constexpr int kCand = 128;                                    // candidate queue of a wave
+// pairs per lane and pass of the test loop.  Measured on C4 (ms per frame): 1: 80.0, 2: 83.8, 3: 88.3, 4: 96.6, 6 (3 waves/SIMD): 103.5,
+// 8: 117.7 — a pass cannot cross a segment boundary, and most segments are tiny (the upper cells of the tree hold one of the three
+// large spheres each), so wider passes mostly repeat pairs; more resident waves (5, 6 per SIMD with spills) change nothing
+#ifndef RT_H16_PP
+#define RT_H16_PP 1
+#endif
+constexpr int kPP = RT_H16_PP;
+#ifndef RT_H16_MINWAVES
+#define RT_H16_MINWAVES 4
+#endif
+#ifdef RT_H16_STATS            // diagnostic build (tools/h16_phases.py): cycles per phase, summed over waves
+#define H16_TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
+__device__ unsigned long long g_h16_cyc[8];
+#define H16_ADD(k, t0) do { const unsigned long long now_ = H16_TICK(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_h16_cyc[k], now_ - (t0)); (t0) = now_; } while (0)
+#ifdef RT_H16_COUNTS           // (per-lane atomics: distort every timing of the same run)
+#define H16_CNT(k, v) atomicAdd(&g_h16_cyc[k], (unsigned long long)(v))
+#else
+#define H16_CNT(k, v) ((void)0)
+#endif
+#else
+#define H16_CNT(k, v) ((void)0)
+#define H16_TICK() 0ull
+#define H16_ADD(k, t0) ((void)0)
+#endif
+constexpr int kPlaneStride = 30;                              // binary16 slots per lane in the plane table (15 dwords: an odd stride)
+struct WaveLds {
+    uint2 seg[kPool];                    // (first pair | owner lane << 26, pairs)
+    unsigned pref[kPool];                // exclusive prefix of pairs
+    unsigned long long key[64];          // per owner: t bits << 32 | entry index + 1
+    union {
+        unsigned short tp[64 * kPlaneStride];   // phase 1: per lane, the ray's parameter at every box plane of the tree
+        struct {
+            uint4 ray[128];              // phase 2: per owner (ox,oy,oz,dx) (dy,dz,a,-), every value in both halves of its dword
+            uint2 cq[kCand];             // candidates: (b | disc << 16 as binary16 bits, entry index + 1 << 6 | owner)
+        } p2;
+    } u;
+    unsigned count, pad_[3];
+};
+static_assert(sizeof(WaveLds) % 16 == 0, "WaveLds keeps 16-byte alignment");
+
+RT_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+RT_DEV unsigned wave_excl_scan(unsigned v, unsigned& total) {   // exclusive prefix sum over the 64 lanes
+    unsigned x = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if ((int)(threadIdx.x & 63) >= off) x += y; }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// One queued candidate: the offer of sphere::hit (sphere.h:24-43) for a positive discriminant, merged into its owner's key.
+RT_DEV void candidate_eval(WaveLds& L, const uint2 e) {
+    H16_CNT(5, 1);
+    const int owner = (int)(e.y & 63u);
+    const uint32_t idx1 = e.y >> 6;
+    R hb, hd, ha, hbest;
+    hb.bits = (uint16_t)e.x; hd.bits = (uint16_t)(e.x >> 16);
+    ha.bits = (uint16_t)L.u.p2.ray[2 * owner + 1].z;
+    hbest.bits = (uint16_t)(((const unsigned*)&L.key[owner])[1]);
+    const float b_f = fl(hb), d_f = fl(hd), A = fl(ha), best_f = fl(hbest);
+    const float nb = -b_f;
+    // cheap filter, margin >= 2x its own error (half an ulp of binary16 on sqrt: 4.9e-4 s; float roundings ~1e-7)
+    const float ra = __builtin_amdgcn_rcpf(A);
+    const float s = __builtin_amdgcn_sqrtf(d_f);
+    const float q1 = (nb - s) * ra, q2 = (nb + s) * ra;
+    const float m = (fabsf(nb) + s) * ra * 1e-3f;
+    if (q1 - m >= best_f) return;                             // near root surely not below the best: nothing it offers can win
+    if (q2 + m <= 0.00099945068359375f) return;               // far root surely <= real_t(0.001f): offers nothing
+    H16_CNT(6, 1);
+    const R tmin = rf(0.001f);
+    const R sq16 = rf(sqrtf(d_f));
+    R t = rf((nb - fl(sq16)) / A);                            // float arithmetic on converted operands, one rounding
+    if (!(t > tmin)) {
+        t = rf((nb + sqrtf(d_f)) / A);                        // far root: float sqrt of float(disc), not rounded (sphere.h:36)
+        if (!(t > tmin)) return;
+    }
+    atomicMin(&L.key[owner], ((unsigned long long)t.bits << 32) | idx1);
+}
+
+// the lanes with p set append (b, disc) to the wave's queue: slots from a wave-uniform count, no atomics
+RT_DEV void push_candidates(WaveLds& L, bool p, _Float16 b, _Float16 disc, uint32_t idx1, int owner, unsigned& qn) {
+    const unsigned long long m = __ballot(p);
+    if (m != 0ull) {
+        const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (p) {
+            const uint2 e = make_uint2((uint32_t)__builtin_bit_cast(uint16_t, b) | ((uint32_t)__builtin_bit_cast(uint16_t, disc) << 16), (idx1 << 6) | (uint32_t)owner);
+            if (slot < (unsigned)kCand) L.u.p2.cq[slot] = e;
+            else candidate_eval(L, e);                         // queue full (a burst of positives): in place
+        }
+        qn += (unsigned)__popcll(m);
+    }
+}
+
+// all queued candidates, 64 at a time
+RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
+    wave_sync();
+    const unsigned cnt = min(qn, (unsigned)kCand);
+    for (unsigned base = 0; base < cnt; base += 64u) {
+        const unsigned i = base + (unsigned)lane;
+        if (i < cnt) candidate_eval(L, L.u.p2.cq[i]);
+    }
+    qn = 0u;
+    wave_sync();
+}
+
+struct PairRay { h2 ox, oy, oz, dx, dy, dz, a; };
+
+// Two spheres against one ray (sphere.h:18-22).  A sphere with b > 0 and fl(b*b) > fl(1.02 disc) lies behind the origin:
+// b^2 > 1.018 disc, so sqrtf(disc) < 0.991 b, -b + sqrtf(disc) < 0 and both roots are <= 0 (or NaN): neither passes
+// `> t_min`.  min(disc, eps - min(bb - 1.02 disc, b)) is > 0 exactly when disc > 0 and the sphere is not surely behind
+// (eps = the smallest positive binary16; a NaN anywhere keeps the sphere).
+RT_DEV void pair_math(const PairRay& q, const uint4 p, h2& b, h2& disc, h2& v) {
+    const h2 cx = as_h2(p.x), cy = as_h2(p.y), cz = as_h2(p.z), r2 = as_h2(p.w);
+    const h2 ocx = q.ox - cx, ocy = q.oy - cy, ocz = q.oz - cz;
+    b = (ocx * q.dx + ocy * q.dy) + ocz * q.dz;
+    const h2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
+    const h2 bb = b * b;
+    disc = bb - q.a * cc;
+    const h2 k102 = as_h2(0x3c143c14u), eps = as_h2(0x00010001u);       // 1.0195 (rounds 1.02 down: margin 1.019 stays), 2^-24
+    const h2 u = pk_min(bb - disc * k102, b);
+    v = pk_min(disc, eps - u);
+}
+
+// intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
+RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
+    auto T = [&](int q) { R h; h.bits = tp[(w >> (5 * q)) & 31u]; return fl(h); };
+    float tmin = T(0), tmax = T(1);
+    if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = T(2), tymax = T(3);
+    if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = T(4), tzmax = T(5);
+    if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    return true;
+}
+
+RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, WaveLds& L, const Ray& r, R a, bool live, R& closest, int& best) {
+    const uint4* __restrict__ ent = (const uint4*)T.ent_hot;      // packed pairs (rt_api.hip, octree_upload)
     if (S.ground_valid) {
         int gb = -1;
         sphere_test(r, a, S.list_hot[0], 0, closest, gb);
         if (gb == 0) best = 0;
     }
-    unsigned short* noted = (unsigned short*)(s_nodes + T.n_nodes * 3) + threadIdx.x;      // noted[k * 256]: this lane's k-th visited non-empty node
+    unsigned long long tph = H16_TICK(); (void)tph;
+    const int lane = threadIdx.x & 63;
     int e_best = -1;
     int node = live ? 0 : T.n_nodes;
     const int n_nodes = T.n_nodes;
+    const int np0 = T.h16_np[0], np1 = T.h16_np[1], np2 = T.h16_np[2];
+    unsigned short* tp = L.u.tp + lane * kPlaneStride;
     while (true) {
-        int nr = 0;
-        while (node < n_nodes && nr < kRanges) {
+        if (lane == 0) L.count = 0u;
+        L.key[lane] = (unsigned long long)closest.bits << 32;
+        if (np0 > 0) {
+            // the ray's parameter at every box plane: the quotients intersect_ray_aabb forms, one division per plane
+            const float* __restrict__ pl = T.h16_planes;
+            for (int k = 0; k < np0; ++k) tp[k] = ((rf(pl[k]) - r.o.x) / r.d.x).bits;
+            for (int k = 0; k < np1; ++k) tp[np0 + k] = ((rf(pl[np0 + k]) - r.o.y) / r.d.y).bits;
+            for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = ((rf(pl[np0 + np1 + k]) - r.o.z) / r.d.z).bits;
+        }
+        wave_sync();
+        // ---- phase 1: walk; every visited non-empty node becomes a segment of the pool (or stalls the lane when it is full)
+        while (node < n_nodes) {
             const float4 n0 = s_nodes[node * 3 + 0];
             const float4 n1 = s_nodes[node * 3 + 1];
             const float4 n2 = s_nodes[node * 3 + 2];
-            if (ray_box(r, n0, n1)) {
+            if (np0 > 0 ? ray_box_tab(tp, (uint32_t)__float_as_int(n2.z)) : ray_box(r, n0, n1)) {
                 const int cnt = __float_as_int(n2.x);
+                if (cnt > 0) {
+                    const unsigned slot = atomicAdd(&L.count, 1u);
+                    if (slot >= (unsigned)kPool) break;              // pool full: this node again next round
+                    L.seg[slot] = make_uint2((uint32_t)__float_as_int(n1.w) | ((uint32_t)lane << 26), (uint32_t)cnt);
+                }
                 node = node + 1;
-                if (cnt > 0) { noted[nr * 256] = (unsigned short)(node - 1); ++nr; }
             } else {
                 node = __float_as_int(n1.z);
             }
         }
-        if (__ballot(nr > 0) == 0ull) break;
-        int k = 0, e = 0, e_end = 0;
-        while (true) {
-            if (e >= e_end && k < nr) {
-                const int nd = (int)noted[k * 256]; ++k;
-                e = __float_as_int(s_nodes[nd * 3 + 1].w); e_end = e + __float_as_int(s_nodes[nd * 3 + 2].x);
+        wave_sync();
+        H16_ADD(0, tph);                                             // walk
+        const unsigned n_seg = min(__builtin_amdgcn_readfirstlane(L.count), (unsigned)kPool);
+        if (n_seg == 0u) break;                                      // (then no lane is stalled either)
+        // this lane's ray for whoever tests its spheres (the plane table's space: the walk is over)
+        L.u.p2.ray[2 * lane] = make_uint4(dup16(r.o.x), dup16(r.o.y), dup16(r.o.z), dup16(r.d.x));
+        L.u.p2.ray[2 * lane + 1] = make_uint4(dup16(r.d.y), dup16(r.d.z), dup16(a), 0u);
+        // ---- phase 2: exclusive prefix of the segments' pair counts, kPool/64 segments per lane
+        unsigned total = 0u;
+        {
+            unsigned run = 0u;
+#pragma unroll
+            for (int k = 0; k < kPool / 64; ++k) {
+                const unsigned sidx = (unsigned)(k * 64 + lane);
+                const unsigned c = sidx < n_seg ? L.seg[sidx].y : 0u;       // pairs
+                unsigned tot;
+                const unsigned ex = wave_excl_scan(c, tot);
+                if (sidx < n_seg) L.pref[sidx] = run + ex;
+                run += tot;
             }
-            const bool has = e < e_end;
-            if (__ballot(has) == 0ull) break;
-            if (has) {
-                // up to four entries of the range per pass, their loads in flight together; tested strictly in order
-                const int m = e_end - e;
-                const uint2* __restrict__ ent = (const uint2*)T.ent_hot;
-                const uint2 s0 = ent[e], s1 = ent[m > 1 ? e + 1 : e], s2 = ent[m > 2 ? e + 2 : e], s3 = ent[m > 3 ? e + 3 : e];
-                sphere_test(r, a, s0, e, closest, e_best);
-                if (m > 1) sphere_test(r, a, s1, e + 1, closest, e_best);
-                if (m > 2) sphere_test(r, a, s2, e + 2, closest, e_best);
-                if (m > 3) sphere_test(r, a, s3, e + 3, closest, e_best);
-                e += m > 4 ? 4 : m;
-            }
+            total = run;
         }
+        wave_sync();
+        const unsigned C = (total + 63u) / 64u;
+        const unsigned begin = min((unsigned)lane * C, total), end = min(begin + C, total);
+        unsigned sg = 0u;
+        if (begin < end) {                                           // last segment starting at or before `begin`
+            unsigned lo = 0u, hi = n_seg;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; }
+            }
+            sg = lo;
+        }
+        H16_ADD(1, tph);                                             // prefix + search
+        unsigned cur = begin, seg_end = begin;                       // seg_end == cur: the first pass loads segment sg
+        unsigned base = 0u;
+        int owner = 0;
+        bool have = false;
+        unsigned qn = 0u;                                            // candidates queued (wave-uniform)
+#ifdef RT_H16_STATS
+        unsigned long long c_push = 0, c_drain = 0, c_load = 0;
+#endif
+        PairRay q; q.ox = q.oy = q.oz = q.dx = q.dy = q.dz = q.a = as_h2(0u);
+        while (__ballot(cur < end) != 0ull) {
+            const bool act = cur < end;
+            if (act && cur >= seg_end) {
+                const uint2 sd = L.seg[sg];
+                const unsigned p0 = L.pref[sg];
+                ++sg;
+                seg_end = p0 + sd.y;
+                base = (sd.x & 0x3ffffffu) - p0;                    // pair `cur` of the pool is pair base + cur of the tree
+                const int ow = (int)(sd.x >> 26);
+                if (ow != owner || !have) {
+                    owner = ow; have = true;
+                    const uint4 r0 = L.u.p2.ray[2 * owner], r1 = L.u.p2.ray[2 * owner + 1];
+                    q.ox = as_h2(r0.x); q.oy = as_h2(r0.y); q.oz = as_h2(r0.z); q.dx = as_h2(r0.w);
+                    q.dy = as_h2(r1.x); q.dz = as_h2(r1.y); q.a = as_h2(r1.z);
+                }
+            }
+            // kPP pairs per pass, every lane in step (a lane that has finished repeats pair 0 and holds nothing): loads in
+            // flight together, the four discriminants computed side by side, then the rare positives are queued.  A clamped
+            // index repeats a pair: the same key twice, harmless.
+            const unsigned lim = act ? min(seg_end, end) : 1u;       // > cur
+            const unsigned last = act ? base + lim - 1u : 0u;
+            const unsigned i0 = act ? base + cur : 0u;
+            unsigned ix[kPP]; uint4 e[kPP];
+#pragma unroll
+            for (int k = 0; k < kPP; ++k) { ix[k] = min(i0 + (unsigned)k, last); e[k] = ent[ix[k]]; }
+#ifdef RT_H16_STATS
+            const unsigned long long tl0 = H16_TICK();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            c_load += H16_TICK() - tl0;
+#endif
+            h2 b[kPP], d[kPP], v[kPP];
+#pragma unroll
+            for (int k = 0; k < kPP; ++k) pair_math(q, e[k], b[k], d[k], v[k]);
+            h2 vm = v[0];
+#pragma unroll
+            for (int k = 1; k < kPP; ++k) vm = __builtin_elementwise_max(vm, v[k]);
+#ifdef RT_H16_STATS
+            const unsigned long long tp0 = H16_TICK();
+#endif
+            if (__ballot(act && ((float)vm.x > 0.0f || (float)vm.y > 0.0f)) != 0ull) {
+#pragma unroll
+                for (int k = 0; k < kPP; ++k) {
+                    push_candidates(L, act && (float)v[k].x > 0.0f, b[k].x, d[k].x, ix[k] * 2u + 1u, owner, qn);
+                    push_candidates(L, act && (float)v[k].y > 0.0f, b[k].y, d[k].y, ix[k] * 2u + 2u, owner, qn);
+                }
+            }
+            if (act) cur = min(cur + (unsigned)kPP, lim);
+#ifdef RT_H16_STATS
+            const unsigned long long tp1 = H16_TICK(); c_push += tp1 - tp0;
+#endif
+            if (qn >= 64u) drain_candidates(L, lane, qn);
+#ifdef RT_H16_STATS
+            c_drain += H16_TICK() - tp1;
+#endif
+        }
+        drain_candidates(L, lane, qn);
+#ifdef RT_H16_STATS
+        if (lane == 0) { atomicAdd(&g_h16_cyc[4], c_push); atomicAdd(&g_h16_cyc[5], c_drain); atomicAdd(&g_h16_cyc[6], c_load); }
+#endif
+        H16_ADD(2, tph);                                             // tests
+        // ---- phase 3
+        const unsigned long long k = L.key[lane];
+        closest.bits = (uint16_t)(k >> 32);
+        if ((uint32_t)k != 0u) e_best = (int)(uint32_t)k - 1;
         if (__ballot(node < n_nodes) == 0ull) break;
     }
     if (e_best >= 0) best = T.ent_id[e_best];
@@ -278,14 +548,18 @@ RT_DEV V sky(const Ray& r, const V& att) {                 // main.cu:67-72
     return vmul(att, c);
 }
 
+// LDS: the tree's nodes, then one WaveLds per wave.  (Staging the leaf sphere lists there too — C4's 89 KB of pairs fit next to
+// eight wave areas, one 512-thread block per CU — was built and measured: 97.6 ms against 83.8 ms from L2 at the same pass width:
+// two waves per SIMD instead of four cost the walk and the shading more than the scan gains; the pairs stay in L2.)
 template <bool TREE, int MODE>
-__global__ __launch_bounds__(256) void k_render_h(RenderArgs A) {
+__global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
     if (TREE) {
         const int n4 = A.tree.n_nodes * 3;
         for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
         __syncthreads();
     }
+    WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? A.tree.n_nodes * 3 : 0)) + (threadIdx.x >> 6);     // this wave's area (TREE only)
     const int lane = threadIdx.x & 63;
     const long long n_slots = A.n_local_tiles * 64;
     const long long first_free = (long long)gridDim.x * 256;
@@ -336,11 +610,12 @@ __global__ __launch_bounds__(256) void k_render_h(RenderArgs A) {
         }
     };
     if (ns > 0) begin_pixel();
+    unsigned long long tk0 = H16_TICK(); (void)tk0;
 
     while (__ballot(live) != 0ull) {
         const R a = vdot(r.d, r.d);
         R closest = rf(FLT_MAX); int best = -1;                              // real_t(FLT_MAX) = +inf in binary16
-        if (TREE) closest_tree(A.scene, A.tree, s_nodes, r, a, live, closest, best);
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, *wl, r, a, live, closest, best);
         else closest_list(A.scene, r, a, closest, best);
         if (live) {
             bool done;
@@ -363,6 +638,7 @@ __global__ __launch_bounds__(256) void k_render_h(RenderArgs A) {
             }
         }
     }
+    H16_ADD(3, tk0);                                                 // whole loop
 }
 
 template <bool TREE>
@@ -373,13 +649,14 @@ __global__ __launch_bounds__(256) void k_trace_h(DevScene S, DevTree T, const fl
         for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = T.nodes4[t];
         __syncthreads();
     }
+    WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? T.n_nodes * 3 : 0)) + (threadIdx.x >> 6);
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = gid < n;
     Ray r; r.o = {ri(0), ri(0), ri(0)}; r.d = {ri(0), ri(1), ri(0)};
     if (live) { const float* p = rays + gid * 6; r.o = vload(p); r.d = vload(p + 3); }
     const R a = vdot(r.d, r.d);
     R closest = rf(FLT_MAX); int best = -1;
-    if (TREE) closest_tree(S, T, s_nodes, r, a, live, closest, best);
+    if (TREE) closest_tree(S, T, s_nodes, *wl, r, a, live, closest, best);
     else closest_list(S, r, a, closest, best);
     if (!live) return;
     rt_hit_record h;
@@ -425,7 +702,7 @@ const char* render_kernel_name_h(bool tree, int mode) {
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
-    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) + (size_t)h16::kRanges * 256 * sizeof(unsigned short) : 0;
+    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) + 4 * sizeof(h16::WaveLds) : 0;
     void (*k)(RenderArgs) = tree ? (mode == 0 ? h16::k_render_h<true, 0> : h16::k_render_h<true, 1>)
                                  : (mode == 0 ? h16::k_render_h<false, 0> : h16::k_render_h<false, 1>);
     const unsigned cap = resident_blocks_h((const void*)k, lds);
@@ -437,11 +714,20 @@ hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t
 hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) + (size_t)h16::kRanges * 256 * sizeof(unsigned short) : 0;
+    const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) + 4 * sizeof(h16::WaveLds) : 0;
     if (tree) hipLaunchKernelGGL((h16::k_trace_h<true>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
     else hipLaunchKernelGGL((h16::k_trace_h<false>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
     return hipGetLastError();
 }
+
+#ifdef RT_H16_STATS
+hipError_t read_h16_stats(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(h16::g_h16_cyc), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return e;
+    if (reset) { unsigned long long z[8] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(h16::g_h16_cyc), z, sizeof(z)); }
+    return e;
+}
+#endif
 
 hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y, int nparts, hipStream_t st) {
     const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;

@@ -16,17 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
 
 
-def main():
-    rank, world, port, nx, ny, ns, n, spl, fp16 = [int(a) for a in sys.argv[1:10]]
+def make_gloo_gather(rt, torch, dist, rank, world, nx, ny, px):
+    """an rt_gather_fn (include/rt_amd.h) that moves the parts through host memory and a gloo gather"""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    import rt_amd as rt
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    precision = rt.FP16 if fp16 else rt.FP32
-    px = 6 if fp16 else 12
     hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -52,6 +44,20 @@ def main():
         except Exception as e:                                   # nothing may propagate through the C frame
             print("gather callback:", repr(e), file=sys.stderr, flush=True)
             return 9
+
+    return gather
+
+
+def main():
+    rank, world, port, nx, ny, ns, n, spl, fp16 = [int(a) for a in sys.argv[1:10]]
+    import torch
+    import torch.distributed as dist
+    import rt_amd as rt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    precision = rt.FP16 if fp16 else rt.FP32
+    gather = make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if fp16 else 12)
 
     W = rt.World(n, nx, ny, precision=precision)
     O = rt.Octree(W, spl) if spl > 0 else None

@@ -11,7 +11,7 @@ tmp=$(mktemp)
 for ((k = 0; k < rounds; k++)); do
   for v in "$@"; do
     if [ "$v" = base ]; then unset RT_AMD_LIB; else export RT_AMD_LIB=$root/dd2360-raytracing_amd/variants/lib_$v.so; fi
-    out=$(timeout -k 10 180 python "$root/bench.py" --config "$cfg" --steps 8 --no-cpu-baseline 2>/dev/null) || { echo "$v FAILED"; exit 1; }
+    out=$(timeout -k 10 180 python "$root/bench.py" --config "$cfg" --steps 8 --no-cpu-baseline --no-pmc 2>/dev/null) || { echo "$v FAILED"; exit 1; }
     echo "$out" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d['roofline']['kernel_ms'])" >> $tmp
   done
 done
