@@ -355,9 +355,10 @@ def main():
                                              "%.1f s wall on %d threads (os.cpu_count() = %s, usable = %d)"
                                              % (rows, cfg["nx"], bspp, smp, secs, threads, os.cpu_count(), threads)}
             if cfg["octree"]:
-                v2, secs2, smp2 = cpu_baseline(cfg, threads, True, rows=4 * threads, spp=spp if not cfg.get("fp16") else 8)
+                trows, tspp = (threads, 16) if cfg["spheres"] > 20000 else (4 * threads, 8 if cfg.get("fp16") else spp)
+                v2, secs2, smp2 = cpu_baseline(cfg, threads, True, rows=trows, spp=tspp)
                 out["cpu_baseline_hitTree"] = {"value": round(v2, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                                               "sample": "%d rows x %d px (%d samples), oracle hitTree path, %.1f s wall" % (4 * threads, cfg["nx"], smp2, secs2)}
+                                               "sample": "%d rows x %d px x %d spp (%d samples), oracle hitTree path, %.1f s wall" % (trows, cfg["nx"], tspp, smp2, secs2)}
         print(json.dumps(out), flush=True)
     if M is not None:
         fence()

@@ -2,8 +2,10 @@
 //
 // Same names and constructor arguments as the reference (vec3.h, ray.h, hitable.h, sphere.h, hitable_list.h,
 // material.h, camera.h, acceleration_structure.h) so that a main.cu-style program builds its scene the same way;
-// the objects describe the scene and serialise to the PODs of include/rt_amd.h.  Intersection, scattering and
-// ray generation run only on the GPU (csrc/rt_kernels.hip): these classes carry no CPU render path.
+// the objects describe the scene and serialise to the PODs of include/rt_amd.h.  The interfaces are callable on the host
+// as well — hitable::hit (hitable.h:19), material::scatter (material.h:49), camera::get_ray (camera.h:45), with the
+// reference's argument lists and the numeric contract of the kernels — for host-side picking, scene checks and tests;
+// rendering itself runs only on the GPU (csrc/rt_kernels.hip): no rt_* entry point ever calls them.
 //
 // Everything is a template over real_t (float or rt::half_t) because the reference selects real_t at compile
 // time (precision_types.h:8) while this library selects it per call.
@@ -43,29 +45,107 @@ template <class R> vec3_t<R> cross(const vec3_t<R>& a, const vec3_t<R>& b) {
     return vec3_t<R>(a.e[1] * b.e[2] - a.e[2] * b.e[1], negate<R>(a.e[0] * b.e[2] - a.e[2] * b.e[0]), a.e[0] * b.e[1] - a.e[1] * b.e[0]);
 }
 template <class R> vec3_t<R> unit_vector(const vec3_t<R>& v) { return v / v.length(); }
+template <class R> vec3_t<R> operator*(const vec3_t<R>& a, const vec3_t<R>& b) { return vec3_t<R>(a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2]); }
+
+// ---------------------------------------------------------------------------------------------- ray (ray.h:6-17), hit_record (hitable.h:9-15)
+template <class R> class ray_t {
+public:
+    ray_t() {}
+    ray_t(const vec3_t<R>& a, const vec3_t<R>& b) : A(a), B(b) {}
+    vec3_t<R> origin() const { return A; }
+    vec3_t<R> direction() const { return B; }
+    vec3_t<R> point_at_parameter(R t) const { return A + t * B; }
+    vec3_t<R> A, B;
+};
+template <class R> class material_t;
+template <class R> struct hit_record_t {
+    R t;
+    vec3_t<R> p, normal;
+    const material_t<R>* mat_ptr;
+};
+
+struct xorwow;
+template <class R> vec3_t<R> random_in_unit_sphere(rt_rand_state* local_rand_state);       // material.h:35-41 (below, after the RNG)
+// pow((1.0f - cosine), 5.0f) of schlick (material.h:14).  Contract shared with the kernels: binary64 ((x*x)*(x*x))*x, rounded once.
+inline float pow5(float x) { const double v = (double)x; const double v2 = v * v; return (float)((v2 * v2) * v); }
 
 // ---------------------------------------------------------------------------------------------- materials (material.h:47-116)
+// Expressions of the reference that mix float and real_t are written out with their C++ conversions (as_float / real_from),
+// so one body serves both real types: with R = float every conversion is the identity.
+template <class R> R sqrt_real(R x) { return real_from<R>(sqrtf(as_float(x))); }            // real_t::sqrt / sqrt(real_t)
+template <class R> vec3_t<R> reflect(const vec3_t<R>& v, const vec3_t<R>& n) { return v - (real_from<R>(2.0f) * dot(v, n)) * n; }   // material.h:43-45
+template <class R> bool refract(const vec3_t<R>& v, const vec3_t<R>& n, R ni_over_nt, vec3_t<R>& refracted) {                       // material.h:17-31
+    const vec3_t<R> uv = unit_vector(v);
+    const R dt = dot(uv, n);
+    const R discriminant = real_from<R>(1.0f) - ni_over_nt * ni_over_nt * (real_from<R>(1.0f) - dt * dt);
+    if (discriminant > real_from_int<R>(0)) { refracted = ni_over_nt * (uv - dt * n) - sqrt_real(discriminant) * n; return true; }
+    return false;
+}
+template <class R> R schlick(R cosine, R ref_idx) {                                                                                 // material.h:11-15
+    R r0 = real_from<R>(1.0f - as_float(ref_idx)) / real_from<R>(1.0f + as_float(ref_idx));
+    r0 = r0 * r0;
+    return r0 + real_from<R>(1.0f - as_float(r0)) * real_from<R>(pow5(1.0f - as_float(cosine)));
+}
+float curand_uniform_of(rt_rand_state* s);      // curand_uniform on the XORWOW state (below)
+
 template <class R> class material_t {
 public:
     virtual ~material_t() {}
-    virtual void describe(rt_sphere& out) const = 0;     // scatter() itself runs on the GPU
+    virtual void describe(rt_sphere& out) const = 0;
+    // material::scatter (material.h:49): attenuation and scattered ray of a hit; false = absorbed
+    virtual bool scatter(const ray_t<R>& r_in, const hit_record_t<R>& rec, vec3_t<R>& attenuation, ray_t<R>& scattered, rt_rand_state* local_rand_state) const = 0;
 };
 template <class R> class lambertian_t : public material_t<R> {
 public:
     explicit lambertian_t(const vec3_t<R>& a) : albedo(a) {}
     void describe(rt_sphere& o) const override { o.material = RT_MAT_LAMBERTIAN; for (int k = 0; k < 3; ++k) o.albedo[k] = as_float(albedo.e[k]); o.param = 0.f; }
+    bool scatter(const ray_t<R>&, const hit_record_t<R>& rec, vec3_t<R>& attenuation, ray_t<R>& scattered, rt_rand_state* local_rand_state) const override {   // material.h:55-60
+        const vec3_t<R> target = (rec.p + rec.normal) + random_in_unit_sphere<R>(local_rand_state);
+        scattered = ray_t<R>(rec.p, target - rec.p);
+        attenuation = albedo;
+        return true;
+    }
     vec3_t<R> albedo;
 };
 template <class R> class metal_t : public material_t<R> {
 public:
     metal_t(const vec3_t<R>& a, R f) : albedo(a) { if (f < real_from<R>(1.0f)) fuzz = f; else fuzz = real_from<R>(1.0f); }   // material.h:66
     void describe(rt_sphere& o) const override { o.material = RT_MAT_METAL; for (int k = 0; k < 3; ++k) o.albedo[k] = as_float(albedo.e[k]); o.param = as_float(fuzz); }
+    bool scatter(const ray_t<R>& r_in, const hit_record_t<R>& rec, vec3_t<R>& attenuation, ray_t<R>& scattered, rt_rand_state* local_rand_state) const override {   // material.h:68-73
+        const vec3_t<R> reflected = reflect(unit_vector(r_in.direction()), rec.normal);
+        scattered = ray_t<R>(rec.p, reflected + fuzz * random_in_unit_sphere<R>(local_rand_state));      // the draw happens even with fuzz 0
+        attenuation = albedo;
+        return dot(scattered.direction(), rec.normal) > real_from<R>(0.0f);
+    }
     vec3_t<R> albedo; R fuzz;
 };
 template <class R> class dielectric_t : public material_t<R> {
 public:
     explicit dielectric_t(R ri) : ref_idx(ri) {}
     void describe(rt_sphere& o) const override { o.material = RT_MAT_DIELECTRIC; o.albedo[0] = o.albedo[1] = o.albedo[2] = 0.f; o.param = as_float(ref_idx); }
+    bool scatter(const ray_t<R>& r_in, const hit_record_t<R>& rec, vec3_t<R>& attenuation, ray_t<R>& scattered, rt_rand_state* local_rand_state) const override {   // material.h:81-113
+        vec3_t<R> outward_normal;
+        const vec3_t<R> reflected = reflect(r_in.direction(), rec.normal);       // the direction is NOT normalised here
+        R ni_over_nt;
+        attenuation = vec3_t<R>(real_from_double<R>(1.0), real_from_double<R>(1.0), real_from_double<R>(1.0));
+        vec3_t<R> refracted(real_from_int<R>(0), real_from_int<R>(0), real_from_int<R>(0));
+        R reflect_prob, cosine;
+        if (dot(r_in.direction(), rec.normal) > real_from<R>(0.0f)) {
+            outward_normal = vec3_t<R>(negate<R>(rec.normal.e[0]), negate<R>(rec.normal.e[1]), negate<R>(rec.normal.e[2]));
+            ni_over_nt = ref_idx;
+            cosine = dot(r_in.direction(), rec.normal) / r_in.direction().length();
+            cosine = sqrt_real(real_from<R>(1.0f) - ref_idx * ref_idx * (real_from<R>(1.0f) - cosine * cosine));   // no clamp: NaN possible, kept
+        } else {
+            outward_normal = rec.normal;
+            ni_over_nt = real_from<R>(1.0f) / ref_idx;
+            cosine = real_from<R>(-as_float(dot(r_in.direction(), rec.normal)) / as_float(r_in.direction().length()));   // float negate, float divide
+        }
+        if (refract(r_in.direction(), outward_normal, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ref_idx);
+        else reflect_prob = real_from<R>(1.0f);
+        if (curand_uniform_of(local_rand_state) < as_float(reflect_prob)) scattered = ray_t<R>(rec.p, reflected);     // exactly one draw
+        else scattered = ray_t<R>(rec.p, refracted);
+        return true;
+    }
     R ref_idx;
 };
 
@@ -74,6 +154,7 @@ template <class R> class hitable_t {             // hitable.h:17-20
 public:
     virtual ~hitable_t() {}
     virtual void describe(rt_sphere& out) const = 0;
+    virtual bool hit(const ray_t<R>& r, R t_min, R t_max, hit_record_t<R>& rec) const = 0;     // hitable.h:19
 };
 template <class R> class sphere_t : public hitable_t<R> {      // sphere.h:7-15
 public:
@@ -85,6 +166,28 @@ public:
         if (mat_ptr) mat_ptr->describe(o);
         else { o.material = RT_MAT_NONE; o.albedo[0] = o.albedo[1] = o.albedo[2] = 0.f; o.param = 0.f; }
     }
+    // sphere::hit (sphere.h:17-46).  A slot without a material (a "ghost" of the world list) is never hit.
+    bool hit(const ray_t<R>& r, R t_min, R t_max, hit_record_t<R>& rec) const override {
+        if (!mat_ptr) return false;
+        const vec3_t<R> oc = r.origin() - center;
+        const R a = dot(r.direction(), r.direction());
+        const R b = dot(oc, r.direction());
+        const R c = dot(oc, oc) - radius * radius;
+        const R discriminant = b * b - a * c;
+        if (discriminant > real_from_int<R>(0)) {
+            R temp = real_from<R>((-as_float(b) - as_float(sqrt_real(discriminant))) / as_float(a));     // float arithmetic on converted operands, one rounding
+            if (temp < t_max && temp > t_min) { fill(rec, r, temp); return true; }
+            temp = real_from<R>((-as_float(b) + sqrtf(as_float(discriminant))) / as_float(a));            // the far root's sqrt is not rounded to real_t (sphere.h:36)
+            if (temp < t_max && temp > t_min) { fill(rec, r, temp); return true; }
+        }
+        return false;
+    }
+    void fill(hit_record_t<R>& rec, const ray_t<R>& r, R t) const {
+        rec.t = t;
+        rec.p = r.point_at_parameter(rec.t);
+        rec.normal = (rec.p - center) / radius;
+        rec.mat_ptr = mat_ptr.get();
+    }
     vec3_t<R> center; R radius; std::shared_ptr<material_t<R>> mat_ptr;
 };
 template <class R> class hitable_list_t : public hitable_t<R> {   // hitable_list.h:7-14
@@ -93,6 +196,16 @@ public:
     hitable_list_t(hitable_t<R>** l, int n) : list(l), list_size(n) {}
     void describe(rt_sphere&) const override {}
     void serialise(rt_sphere* out) const { for (int i = 0; i < list_size; ++i) list[i]->describe(out[i]); }
+    // hitable_list::hit (hitable_list.h:16-31): every entry in list order, closest so far as t_max
+    bool hit(const ray_t<R>& r, R t_min, R t_max, hit_record_t<R>& rec) const override {
+        hit_record_t<R> temp_rec;
+        bool hit_anything = false;
+        R closest_so_far = t_max;
+        for (int i = 0; i < list_size; i++) {
+            if (list[i]->hit(r, t_min, closest_so_far, temp_rec)) { hit_anything = true; closest_so_far = temp_rec.t; rec = temp_rec; }
+        }
+        return hit_anything;
+    }
     hitable_t<R>** list; int list_size;
 };
 
@@ -121,6 +234,18 @@ public:
         lower_left_corner = origin - (half_width * focus_dist) * u - (half_height * focus_dist) * v - focus_dist * w;
         horizontal = (real_from<R>(2.0f) * half_width * focus_dist) * u;
         vertical = (real_from<R>(2.0f) * half_height * focus_dist) * v;
+    }
+    // camera::get_ray (camera.h:45-49) with random_in_unit_disk (camera.h:12-18): two draws per try
+    ray_t<R> get_ray(R s, R t, rt_rand_state* local_rand_state) const {
+        vec3_t<R> p;
+        do {
+            const float x = curand_uniform_of(local_rand_state);            // x before y
+            const float y = curand_uniform_of(local_rand_state);
+            p = real_from<R>(2.0f) * vec3_t<R>(real_from<R>(x), real_from<R>(y), real_from_int<R>(0)) - vec3_t<R>(real_from_int<R>(1), real_from_int<R>(1), real_from_int<R>(0));
+        } while (dot(p, p) >= real_from<R>(1.0f));
+        const vec3_t<R> rd = lens_radius * p;
+        const vec3_t<R> offset = rd.x() * u + rd.y() * v;
+        return ray_t<R>(origin + offset, lower_left_corner + s * horizontal + t * vertical - origin - offset);
     }
     void serialise(rt_camera& c) const {
         for (int k = 0; k < 3; ++k) {
@@ -155,6 +280,18 @@ struct xorwow {
         return scaled + (2.3283064e-10f / 2.0f);
     }
 };
+
+inline float curand_uniform_of(rt_rand_state* s) { return xorwow::uniform(*s); }
+template <class R> vec3_t<R> random_in_unit_sphere(rt_rand_state* local_rand_state) {       // material.h:35-41: three draws per try, x y z
+    vec3_t<R> p;
+    do {
+        const float x = curand_uniform_of(local_rand_state);
+        const float y = curand_uniform_of(local_rand_state);
+        const float z = curand_uniform_of(local_rand_state);
+        p = real_from<R>(2.0f) * vec3_t<R>(real_from<R>(x), real_from<R>(y), real_from<R>(z)) - vec3_t<R>(real_from_int<R>(1), real_from_int<R>(1), real_from_int<R>(1));
+    } while (p.squared_length() >= real_from<R>(1.0f));
+    return p;
+}
 
 // ---------------------------------------------------------------------------------------------- create_world (main.cu:146-204)
 template <class R> struct world_t {
