@@ -44,19 +44,19 @@ struct AccelHost {
 };
 
 // constants of the exactness argument
-static const double kZone = 24.0;          // near zone: |o - (0,1,0)| <= kZone
-static const double kCentreBound = 17.5;   // grid spheres have |c - (0,1,0)| <= this (root box grown by the radius)
-static const double kSlack = 2e-3;         // rasterisation slack (absorbs float error of the walk, ~1e-5)
+constexpr double kZone = 24.0;          // near zone: |o - (0,1,0)| <= kZone
+constexpr double kCentreBound = 17.5;   // grid spheres have |c - (0,1,0)| <= this (root box grown by the radius)
+constexpr double kSlack = 2e-3;         // rasterisation slack (absorbs float error of the walk, ~1e-5)
 // "brick" of a sphere = the box of level-3 cells [ix0..ix1] x [iy0..iy1] x [iz0..iz1] when EVERY cell of that box stores the
 // sphere.  A hit point that keeps 0.002 from the brick's six outer faces lies in a stored cell whose slab test passes
 // (the float interval ends, the kernel's hit point and its cell coordinates are together off by less
 // than 1e-5 for |o| <= 25, so 0.002 is a 200-fold margin).  In cell units (cells are 2.75 x 0.25 x 2.75): 7.3e-4 / 8e-3,
 // rounded up.  (0.012 cost 2.7 % of the C3 frame: the lowest 3 % of a sphere resting on y = 0 fell outside its brick.)
-static const double kBrickMxz = 0.0008, kBrickMy = 0.0085;
+constexpr double kBrickMxz = 0.0008, kBrickMy = 0.0085;
 // 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
-static inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
+__host__ __device__ inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
 // inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
-static inline double accel_Rp(double r2) { return std::sqrt(r2 * (1.0 + 1e-6) + accel_K2()) + 1e-5 + kSlack; }
+__host__ __device__ inline double accel_Rp(double r2) { return sqrt(r2 * (1.0 + 1e-6) + accel_K2()) + 1e-5 + kSlack; }
 
 // nodes/ent_id: the pre-order traversal copy; geom_r2(i) gives (cx,cy,cz,r^2) of world-list index i
 // list_mode: `nodes` is the single unbounded node that stands for hitable_list::hit (every sphere is eligible everywhere:

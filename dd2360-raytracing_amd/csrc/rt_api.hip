@@ -9,9 +9,7 @@
 #include <new>
 #include <limits>
 #include <algorithm>
-#include "rt_device.h"
-#include "../host/rt_scene.hpp"
-#include "rt_accel.h"
+#include "rt_handles.h"
 
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
@@ -24,6 +22,7 @@ hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st);
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc);
+namespace gpubuild { int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int spl, hipStream_t st); }
 const char* render_kernel_name_h(bool tree, int mode);
 #ifdef RT_H16_STATS
 hipError_t read_h16_stats(unsigned long long* out, int reset);
@@ -37,61 +36,6 @@ hipError_t read_wave_dbg(unsigned long long* out);
 using namespace rt;
 
 #define RT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
-
-// Handles keep their host staging copy; device buffers are created by rt_world_upload / rt_octree_upload
-// (called implicitly by the first render/trace that uses the handle).  A handle passed as `const` to a compute call stays
-// logically constant: what such a call may create lazily (device copies, the list grid, the default render context) lives
-// behind a pointer in a `Lazy` block of its own.
-struct rt_octree;
-
-// Per-launch state of rt_render: work counters, scheduling workspace, timing events.  One context serves one launch at a
-// time: calls on the same context are ordered by the library (an event recorded behind the render kernel, which the next
-// call's stream waits for before it touches the workspace), so two streams sharing a context serialise instead of racing;
-// give concurrent frames a context each (rt_render_ctx_create).
-struct rt_render_ctx {
-    // work counters of the persistent render kernel: a ring of slots (one per launch, 64 B apart), zeroed on the stream
-    unsigned int* d_queue = nullptr; unsigned launches = 0;
-    // scheduling workspace (tile costs, hand-out order, long-chain flags and list), grown on demand
-    int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
-    // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_render_ctx_times
-    hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
-    // ordering of successive launches that share this context
-    hipEvent_t done = nullptr; hipStream_t last_stream = nullptr; bool has_done = false;
-};
-static const unsigned kQueueSlots = 64, kQueueStride = 16;
-
-struct rt_world {
-    int precision = RT_PRECISION_FP32;
-    int n = 0;
-    std::vector<float4> h_hot, h_geom, h_mat;
-    std::vector<int32_t> h_ids, h_kind;
-    int list_traversal = RT_TRAVERSAL_FAST;
-    struct Lazy {
-        bool uploaded = false;
-        DevScene dev{};
-        void* d_list_hot = nullptr; void* d_list_id = nullptr; void* d_geom = nullptr; void* d_mat = nullptr; void* d_kind = nullptr;
-        // hitable_list::hit through the candidate grid: the list as a one-node "tree" (fp32 only; null = plain scan)
-        rt_octree* list_tree = nullptr; bool list_tree_tried = false;
-        rt_render_ctx ctx;                      // the context rt_render / rt_render_progressive use
-    };
-    Lazy* z = nullptr;
-};
-
-struct rt_octree {
-    int precision = RT_PRECISION_FP32;
-    Octree* host = nullptr;
-    std::vector<DevNode> h_nodes; std::vector<float4> h_ent_hot; std::vector<int32_t> h_ent_id;
-    AccelHost accel;
-    int traversal = RT_TRAVERSAL_FAST;
-    struct Lazy {
-        bool uploaded = false;
-        DevTree dev{};
-        void* d_nodes = nullptr; void* d_ent_hot = nullptr; void* d_ent_id = nullptr;
-        void* d_acc[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // large_hot, large_brick, cs, hot, brick, memb_start, memb_cell, -, cellnode, bits_index, cellbits
-    };
-    Lazy* z = nullptr;
-    int n_nodes = 0, n_entries = 0;
-};
 
 // device copy of a host vector into *d.  A buffer that exists already (an earlier upload attempt got that far) is kept;
 // on failure nothing allocated here is left behind.
@@ -158,11 +102,8 @@ static float radius_squared(const rt_sphere& s, int precision) {
 }
 
 template <class R> static int create_world_impl(rt_sphere* list, int num_spheres, float sphere_radius, rt_camera* cam, int nx, int ny, rt_rand_state* st, int* num_created) {
-    world_t<R> W;
-    create_world<R>(W, num_spheres, sphere_radius, nx, ny, st);
-    W.d_world.serialise(list);
-    W.d_camera.serialise(*cam);
-    if (num_created) *num_created = W.created;
+    const int created = create_world_pods<R>(list, num_spheres, sphere_radius, cam, nx, ny, st);
+    if (num_created) *num_created = created;
     return 0;
 }
 
@@ -408,6 +349,7 @@ int rt_build_octree(const rt_sphere* list, int num_hitables, int spheres_per_lea
         flatten(*O->host, list, precision, 0, O->h_nodes, O->h_ent_hot, O->h_ent_id);
         O->n_nodes = (int)O->h_nodes.size(); O->n_entries = (int)O->h_ent_id.size();
         build_accel(O->accel, O->h_nodes, O->h_ent_id, O->h_ent_hot, num_hitables);
+        O->n_world = num_hitables; O->bit_rows = (int)(O->accel.cellbits.size() / 16);
         if (precision != RT_PRECISION_FP32) O->accel.p.enabled = 0;      // the error bounds behind the grid are binary32 bounds
     } catch (const std::bad_alloc&) { rt_free_octree(O); return RT_ENOMEM; }
     *out = O;
@@ -521,8 +463,8 @@ int rt_octree_accel_info(const rt_octree* O, int* grid_dim, float* cell_size, in
 // traversal copy (pre-order nodes with skip links, entry -> sphere index) for inspection
 int rt_octree_flat_info(const rt_octree* O, int* n_nodes, int* n_entries) {
     if (!O) return RT_EINVAL;
-    if (n_nodes) *n_nodes = (int)O->h_nodes.size();
-    if (n_entries) *n_entries = (int)O->h_ent_id.size();
+    if (n_nodes) *n_nodes = O->n_nodes;
+    if (n_entries) *n_entries = O->n_entries;
     return 0;
 }
 
@@ -533,6 +475,7 @@ int rt_free_octree(rt_octree* O) {
         void* bufs[3] = {O->z->d_nodes, O->z->d_ent_hot, O->z->d_ent_id};
         rc = free_all(bufs, 3);
         const int r2 = free_all(O->z->d_acc, 12); if (!rc) rc = r2;
+        if (O->z->d_arena) { const hipError_t e = hipFree(O->z->d_arena); if (e != hipSuccess && !rc) rc = (int)e; }
         delete O->z;
     }
     delete O->host;      // the reference frees a new'ed Octree with free() (main.cu:473); here new/delete match
@@ -540,8 +483,38 @@ int rt_free_octree(rt_octree* O) {
     return rc;
 }
 
+// reference-layout view of a tree built on the device: downloaded when an inspection call first asks for it
+static int ensure_host_view(const rt_octree* O) {
+    if (O->host) return 0;
+    rt_octree::Lazy& Z = *O->z;
+    if (!Z.d_ref_nodes) return RT_EINVAL;
+    Octree* T = new (std::nothrow) Octree();
+    if (!T) return RT_ENOMEM;
+    try {
+        T->spl = Z.ref_spl; T->nodeCount = Z.ref_node_count; T->leafCount = Z.ref_leaf_count;
+        T->dropped_full = Z.ref_dropped_full; T->dropped_outside = Z.ref_dropped_outside;
+        T->nodes.resize(RT_OCTREE_MAX_NODES); T->leaf_count.resize(T->leafCount); T->leaf_indices.resize((size_t)T->leafCount * T->spl);
+    } catch (const std::bad_alloc&) { delete T; return RT_ENOMEM; }
+    hipError_t e = hipMemcpy(T->nodes.data(), Z.d_ref_nodes, sizeof(rt_octnode) * RT_OCTREE_MAX_NODES, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(T->leaf_count.data(), Z.d_leaf_count, sizeof(int32_t) * (size_t)T->leafCount, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(T->leaf_indices.data(), Z.d_leaf_indices, sizeof(int32_t) * (size_t)T->leafCount * T->spl, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { delete T; return (int)e; }
+    const_cast<rt_octree*>(O)->host = T;          // (the one cached view of a handle that is otherwise read-only here)
+    return 0;
+}
+
 int rt_octree_info(const rt_octree* O, int* node_count, int* leaf_count, int* spheres_per_leaf, int* dropped_full, int* dropped_outside) {
-    if (!O || !O->host) return RT_EINVAL;
+    if (!O) return RT_EINVAL;
+    if (!O->host && O->z && O->z->d_ref_nodes) {                      // device-built: the counts came back with the build
+        const rt_octree::Lazy& Z = *O->z;
+        if (node_count) *node_count = Z.ref_node_count;
+        if (leaf_count) *leaf_count = Z.ref_leaf_count;
+        if (spheres_per_leaf) *spheres_per_leaf = Z.ref_spl;
+        if (dropped_full) *dropped_full = Z.ref_dropped_full;
+        if (dropped_outside) *dropped_outside = Z.ref_dropped_outside;
+        return 0;
+    }
+    if (!O->host) return RT_EINVAL;
     if (node_count) *node_count = O->host->nodeCount;
     if (leaf_count) *leaf_count = O->host->leafCount;
     if (spheres_per_leaf) *spheres_per_leaf = O->host->spl;
@@ -550,15 +523,82 @@ int rt_octree_info(const rt_octree* O, int* node_count, int* leaf_count, int* sp
     return 0;
 }
 int rt_octree_nodes(const rt_octree* O, rt_octnode* out_nodes) {
-    if (!O || !O->host || !out_nodes) return RT_EINVAL;
+    if (!O || !out_nodes) return RT_EINVAL;
+    const int rc = ensure_host_view(O);
+    if (rc) return rc;
     memcpy(out_nodes, O->host->nodes.data(), sizeof(rt_octnode) * RT_OCTREE_MAX_NODES);
     return 0;
 }
 int rt_octree_leaves(const rt_octree* O, int32_t* counts, int32_t* indices) {
-    if (!O || !O->host || !counts || !indices) return RT_EINVAL;
+    if (!O || !counts || !indices) return RT_EINVAL;
+    const int rc = ensure_host_view(O);
+    if (rc) return rc;
     memcpy(counts, O->host->leaf_count.data(), sizeof(int32_t) * O->host->leafCount);
     memcpy(indices, O->host->leaf_indices.data(), sizeof(int32_t) * (size_t)O->host->leafCount * O->host->spl);
     return 0;
+}
+
+// One device array of an uploaded FP32 tree, copied to the host (parity checks of the device build against the host build):
+// 0 nodes, 1 ent_hot, 2 ent_id, 3 large_hot, 4 large_brick, 5 cs, 6 hot, 7 brick, 8 memb_start, 9 memb_cell, 10 cellnode,
+// 11 bits_index, 12 cellbits.  *bytes receives the array's size; the copy happens when cap suffices.
+int rt_octree_debug_array(const rt_octree* O, int which, void* out, size_t cap, size_t* bytes) {
+    if (!O || !bytes || O->precision != RT_PRECISION_FP32) return RT_EINVAL;
+    const int rc = octree_upload(O);
+    if (rc) return rc;
+    const rt_octree::Lazy& Z = *O->z;
+    const DevAccel& p = Z.dev.acc;
+    const size_t total = O->accel.n_entries, ncell = (size_t)O->accel.p.G * O->accel.p.G, nl = (size_t)O->accel.p.n_large;
+    const void* src = nullptr; size_t sz = 0;
+    switch (which) {
+        case 0: src = Z.dev.nodes4; sz = (size_t)O->n_nodes * sizeof(DevNode); break;
+        case 1: src = Z.dev.ent_hot; sz = (size_t)O->n_entries * 16; break;
+        case 2: src = Z.dev.ent_id; sz = (size_t)O->n_entries * 4; break;
+        case 3: src = p.large_hot; sz = nl * 16; break;
+        case 4: src = p.large_brick; sz = (nl ? nl : 1) * 32; break;
+        case 5: src = p.cs; sz = O->accel.p.enabled || total ? 2 * (ncell + 1) * 4 : 0; break;
+        case 6: src = p.hot; sz = O->accel.p.G ? (2 * total + 16) * 16 : 0; break;
+        case 7: src = p.brick; sz = O->accel.p.G ? (2 * total + 16) * 32 : 0; break;
+        case 8: src = p.memb_start; sz = ((size_t)O->n_world + 1) * 4; break;
+        case 9: src = p.memb_cell; sz = (size_t)O->n_entries * 4; break;
+        case 10: src = p.cellnode; sz = 512 * 4; break;
+        case 11: src = p.bits_index; sz = (size_t)O->n_world * 4; break;
+        case 12: src = p.cellbits; sz = (size_t)O->bit_rows * 64; break;
+        default: return RT_EINVAL;
+    }
+    *bytes = sz;
+    if (!out || cap < sz || sz == 0 || !src) return 0;
+    return (int)hipMemcpy(out, src, sz, hipMemcpyDeviceToHost);
+}
+
+// buildOctree + traversal copy + candidate grid on the device, from the world's device-resident sphere list (rt_build.hip).
+// Binary16 worlds, and inputs the device build declines, are built on the host from the world's own copy of the list.
+int rt_build_octree_gpu(const rt_world* world, int spheres_per_leaf, rt_octree** out, void* stream) {
+    if (!world || !out || spheres_per_leaf <= 0) return RT_EINVAL;
+    *out = nullptr;
+    if (world->precision == RT_PRECISION_FP32) {
+        int rc = world_upload(world);
+        if (rc) return rc;
+        rt_octree* O = new (std::nothrow) rt_octree();
+        if (!O) return RT_ENOMEM;
+        O->z = new (std::nothrow) rt_octree::Lazy();
+        if (!O->z) { delete O; return RT_ENOMEM; }
+        O->precision = RT_PRECISION_FP32;
+        rc = gpubuild::build(O, (const float4*)world->z->d_geom, (const int32_t*)world->z->d_kind, world->n, spheres_per_leaf, (hipStream_t)stream);
+        if (rc == 0) { *out = O; return 0; }
+        (void)rt_free_octree(O);
+        if (rc != RT_ENOTSUP) return rc;
+    }
+    std::vector<rt_sphere> list;
+    try {
+        list.resize((size_t)world->n);
+        for (int i = 0; i < world->n; ++i) {
+            rt_sphere& s = list[i];
+            const float4 g = world->h_geom[i], m = world->h_mat[i];
+            s.center[0] = g.x; s.center[1] = g.y; s.center[2] = g.z; s.radius = g.w;
+            s.material = world->h_kind[i]; s.albedo[0] = m.x; s.albedo[1] = m.y; s.albedo[2] = m.z; s.param = m.w;
+        }
+    } catch (const std::bad_alloc&) { return RT_ENOMEM; }
+    return rt_build_octree(list.data(), world->n, spheres_per_leaf, world->precision, out);
 }
 
 // ------------------------------------------------------------------------------------------------ the hot path

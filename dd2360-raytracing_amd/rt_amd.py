@@ -53,6 +53,8 @@ SYMBOLS = {
     "rt_free_world": (_i, [_vp]),
     "rt_build_octree": (_i, [_vp, _i, _i, _i, _vp]),
     "rt_octree_upload": (_i, [_vp]),
+    "rt_build_octree_gpu": (_i, [_vp, _i, _vp, _vp]),
+    "rt_octree_debug_array": (_i, [_vp, _i, _vp, C.c_size_t, _vp]),
     "rt_free_octree": (_i, [_vp]),
     "rt_octree_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rt_octree_flat_info": (_i, [_vp, _vp, _vp]),
@@ -306,11 +308,15 @@ class World:
 class Octree:
     """buildOctree (acceleration_structure.h:195) + upload (main.cu:413-417)."""
 
-    def __init__(self, world, spheres_per_leaf=30):
+    def __init__(self, world, spheres_per_leaf=30, gpu=False):
+        """gpu=True: rt_build_octree_gpu (built on the device from the world's device copy, ready to render)"""
         L = lib()
         self.world, self.spl = world, spheres_per_leaf
         h = C.c_void_p()
-        check(L.rt_build_octree(_np(world.spheres), world.num_spheres, spheres_per_leaf, world.precision, C.byref(h)), "rt_build_octree")
+        if gpu:
+            check(L.rt_build_octree_gpu(world.h, spheres_per_leaf, C.byref(h), _stream()), "rt_build_octree_gpu")
+        else:
+            check(L.rt_build_octree(_np(world.spheres), world.num_spheres, spheres_per_leaf, world.precision, C.byref(h)), "rt_build_octree")
         self.h = h
 
     def upload(self):
@@ -321,6 +327,14 @@ class Octree:
         """TRAVERSAL_REFERENCE (exact bucket scan) or TRAVERSAL_FAST (default, culling grid + fallback)"""
         check(lib().rt_octree_set_traversal(self.h, mode), "rt_octree_set_traversal")
         return self
+
+    def device_array(self, which):
+        """bytes of one device-resident array of the (uploaded) tree, see rt_octree_debug_array"""
+        n = C.c_size_t(0)
+        check(lib().rt_octree_debug_array(self.h, which, None, 0, C.byref(n)), "rt_octree_debug_array")
+        buf = np.zeros(max(1, n.value), np.uint8)
+        check(lib().rt_octree_debug_array(self.h, which, _np(buf), n.value, C.byref(n)), "rt_octree_debug_array")
+        return buf[: n.value]
 
     def accel_info(self):
         g, n, l = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -11,6 +11,7 @@ cd $root
 /opt/rocm/bin/hipcc $F -c -o build/v_$name/h.o csrc/rt_kernels_fp16.hip &
 /opt/rocm/bin/hipcc $F -c -o build/v_$name/a.o csrc/rt_api.hip &
 /opt/rocm/bin/hipcc $F -c -o build/v_$name/m.o csrc/rt_multi.hip &
+/opt/rocm/bin/hipcc $F -c -o build/v_$name/b.o csrc/rt_build.hip &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/lib_$name.so build/v_$name/k.o build/v_$name/l.o build/v_$name/h.o build/v_$name/a.o build/v_$name/m.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/lib_$name.so build/v_$name/k.o build/v_$name/l.o build/v_$name/h.o build/v_$name/a.o build/v_$name/m.o build/v_$name/b.o -ldl
 echo "built variants/lib_$name.so"
