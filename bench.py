@@ -196,13 +196,32 @@ def main():
     kernel_name = rt.render_kernel_name(W, O, 0)                   # the library's own selection, as rocprofv3 names it
     M = None
     if world > 1:
-        if same_gpu:
-            from multi_worker import make_gloo_gather
-            M = rt.Multi(rank, world, gather=make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if cfg.get("fp16") else 12)).reserve(nx, ny, precision, 0)
-        else:
-            ids = [rt.multi_unique_id() if rank == 0 else None]
+        transport = "rccl"
+        if not same_gpu:
+            # RCCL inside librt_amd.so: rank 0 creates the id, every rank joins.  Should any rank fail to join (no RCCL, no
+            # peer access), ALL ranks fall back to the host-staged gloo exchange below, and the line says so.
+            ids = [None]
+            try:
+                ids = [rt.multi_unique_id() if rank == 0 else None]
+            except rt.RtError as e:
+                print("rank 0: %s" % e, file=sys.stderr, flush=True)
             dist.broadcast_object_list(ids, src=0)
-            M = rt.Multi(rank, world, unique_id=ids[0]).reserve(nx, ny, precision, 0)
+            try:
+                M = rt.Multi(rank, world, unique_id=ids[0]) if ids[0] is not None else None
+            except rt.RtError as e:
+                print("rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+                M = None
+            ok = torch.tensor([1 if M is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if M is not None:
+                    M.close()
+                M = None
+        if M is None:
+            from multi_worker import make_gloo_gather
+            transport = "gloo (host-staged)" + ("" if same_gpu else " — RCCL was not available on every rank")
+            M = rt.Multi(rank, world, gather=make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if cfg.get("fp16") else 12))
+        M.reserve(nx, ny, precision, 0)
         full = torch.zeros(nx * ny * 3, dtype=torch.float16 if cfg.get("fp16") else torch.float32, device="cuda") if rank == 0 else None
     else:
         st = rt.alloc_rand_state(nx, ny)
@@ -283,7 +302,7 @@ def main():
             cfg["name"], nx, ny, spp, cfg["spheres"], "on" if cfg["octree"] else "off", cfg["spl"], "USE_FP16" if cfg.get("fp16") else "fp32")
         if world > 1:
             workload += ("; frame grown to %d x 960000 px" % world if weak else "; the fixed frame") + \
-                        ", 8x8 tiles round-robin over %d GPUs (rt_multi_render), one RCCL exchange to rank 0" % world
+                        ", 8x8 tiles round-robin over %d GPUs (rt_multi_render), one exchange to rank 0 over %s" % (world, transport)
         out = {
             "metric": "Msamples/s (W*H*spp/render_time) at %dx%d, %d spheres" % (nx, ny, cfg["spheres"]),
             "value": round(value, 3), "unit": "Msamples/s",
@@ -291,7 +310,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if (world == 1 or weak) else "strong", "vs_baseline": None,
             "dtype": "f16" if cfg.get("fp16") else "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "timed_region": "render_init + render" + (" + RCCL exchange + rt_assemble (one rt_multi_render call per frame)" if world > 1 else "") + ", scene resident in HBM"},
+                       "timed_region": "render_init + render" + (" + framebuffer exchange + rt_assemble (one rt_multi_render call per frame)" if world > 1 else "") + ", scene resident in HBM"},
             "roofline": {"bound": "valu", "kernel": kernel_name,
                          "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,

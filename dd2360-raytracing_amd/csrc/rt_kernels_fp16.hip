@@ -163,6 +163,14 @@ constexpr int kCand = 128;                                    // candidate queue
 #define RT_H16_PP 1
 #endif
 constexpr int kPP = RT_H16_PP;
+// spans a lane steps through side by side (independent loads and arithmetic chains).  C4: 1: 76.0 ms, 2: 75.0, 3: 77.7, 4 (3 waves/SIMD): 78.7
+#ifndef RT_H16_SPANS
+#define RT_H16_SPANS 2
+#endif
+constexpr int kNS = RT_H16_SPANS;
+#ifndef RT_H16_BEHIND
+#define RT_H16_BEHIND 0
+#endif
 #ifndef RT_H16_MINWAVES
 #define RT_H16_MINWAVES 4
 #endif
@@ -260,11 +268,9 @@ RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
 }
 
 struct PairRay { h2 ox, oy, oz, dx, dy, dz, a; };
+struct Span { unsigned cur, end, seg_end, base, sg; int owner; bool have; PairRay q; };      // a lane's walk through one span of the pool
 
-// Two spheres against one ray (sphere.h:18-22).  A sphere with b > 0 and fl(b*b) > fl(1.02 disc) lies behind the origin:
-// b^2 > 1.018 disc, so sqrtf(disc) < 0.991 b, -b + sqrtf(disc) < 0 and both roots are <= 0 (or NaN): neither passes
-// `> t_min`.  min(disc, eps - min(bb - 1.02 disc, b)) is > 0 exactly when disc > 0 and the sphere is not surely behind
-// (eps = the smallest positive binary16; a NaN anywhere keeps the sphere).
+// Two spheres against one ray: the discriminants of sphere.h:18-22 in packed binary16; v > 0 marks a candidate.
 RT_DEV void pair_math(const PairRay& q, const uint4 p, h2& b, h2& disc, h2& v) {
     const h2 cx = as_h2(p.x), cy = as_h2(p.y), cz = as_h2(p.z), r2 = as_h2(p.w);
     const h2 ocx = q.ox - cx, ocy = q.oy - cy, ocz = q.oz - cz;
@@ -272,9 +278,17 @@ RT_DEV void pair_math(const PairRay& q, const uint4 p, h2& b, h2& disc, h2& v) {
     const h2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
     const h2 bb = b * b;
     disc = bb - q.a * cc;
-    const h2 k102 = as_h2(0x3c143c14u), eps = as_h2(0x00010001u);       // 1.0195 (rounds 1.02 down: margin 1.019 stays), 2^-24
+#if RT_H16_BEHIND
+    // A sphere with b > 0 and fl(b*b) > fl(1.02 disc) lies behind the origin: b^2 > 1.018 disc, so sqrtf(disc) < 0.991 b,
+    // -b + sqrtf(disc) < 0 and both roots are <= 0 (or NaN): neither passes `> t_min`.  min(disc, eps - min(bb - 1.02 disc, b))
+    // is > 0 exactly when disc > 0 and the sphere is not surely behind (eps = the smallest positive binary16; a NaN anywhere
+    // keeps the sphere).  Exact, but six packed instructions per pair to drop a fifth of the candidates: C4 75.8 ms with, 76.6 without.
+    const h2 k102 = as_h2(0x3c143c14u), eps = as_h2(0x00010001u);
     const h2 u = pk_min(bb - disc * k102, b);
     v = pk_min(disc, eps - u);
+#else
+    v = disc;
+#endif
 }
 
 // intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
@@ -358,87 +372,82 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             total = run;
         }
         wave_sync();
-        const unsigned C = (total + 63u) / 64u;
-        const unsigned begin = min((unsigned)lane * C, total), end = min(begin + C, total);
-        unsigned sg = 0u;
-        if (begin < end) {                                           // last segment starting at or before `begin`
-            unsigned lo = 0u, hi = n_seg;
+        // every lane takes kNS spans of the pool's concatenated pairs (span j = pairs [j C, (j+1) C)) and steps through them side by
+        // side: kNS loads in flight per lane and kNS independent chains of packed arithmetic (a dependent v_pk_*_f16 issues every
+        // ~9 cycles, independent ones every ~4.5: tools/micro/pk16_rate.hip) without reading past a segment's end
+        const unsigned C = (total + 64u * kNS - 1u) / (64u * kNS);
+        Span sp[kNS];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const unsigned mid = (lo + hi) >> 1;
-                if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; }
+        for (int j = 0; j < kNS; ++j) {
+            Span& S = sp[j];
+            const unsigned begin = min((unsigned)(lane + 64 * j) * C, total);
+            S.end = min(begin + C, total); S.cur = begin; S.seg_end = begin;       // seg_end == cur: the first pass loads segment sg
+            S.base = 0u; S.owner = 0; S.have = false; S.sg = 0u;
+            S.q.ox = S.q.oy = S.q.oz = S.q.dx = S.q.dy = S.q.dz = S.q.a = as_h2(0u);
+            if (begin < S.end) {                                     // last segment starting at or before `begin`
+                unsigned lo = 0u, hi = n_seg;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; }
+                }
+                S.sg = lo;
             }
-            sg = lo;
         }
         H16_ADD(1, tph);                                             // prefix + search
-        unsigned cur = begin, seg_end = begin;                       // seg_end == cur: the first pass loads segment sg
-        unsigned base = 0u;
-        int owner = 0;
-        bool have = false;
         unsigned qn = 0u;                                            // candidates queued (wave-uniform)
-#ifdef RT_H16_STATS
-        unsigned long long c_push = 0, c_drain = 0, c_load = 0;
-#endif
-        PairRay q; q.ox = q.oy = q.oz = q.dx = q.dy = q.dz = q.a = as_h2(0u);
-        while (__ballot(cur < end) != 0ull) {
-            const bool act = cur < end;
-            if (act && cur >= seg_end) {
-                const uint2 sd = L.seg[sg];
-                const unsigned p0 = L.pref[sg];
-                ++sg;
-                seg_end = p0 + sd.y;
-                base = (sd.x & 0x3ffffffu) - p0;                    // pair `cur` of the pool is pair base + cur of the tree
-                const int ow = (int)(sd.x >> 26);
-                if (ow != owner || !have) {
-                    owner = ow; have = true;
-                    const uint4 r0 = L.u.p2.ray[2 * owner], r1 = L.u.p2.ray[2 * owner + 1];
-                    q.ox = as_h2(r0.x); q.oy = as_h2(r0.y); q.oz = as_h2(r0.z); q.dx = as_h2(r0.w);
-                    q.dy = as_h2(r1.x); q.dz = as_h2(r1.y); q.a = as_h2(r1.z);
+        while (true) {
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < kNS; ++j) any = any || sp[j].cur < sp[j].end;
+            if (__ballot(any) == 0ull) break;
+            bool act[kNS]; unsigned ix[kNS][kPP], lim[kNS]; uint4 e[kNS][kPP];
+#pragma unroll
+            for (int j = 0; j < kNS; ++j) {
+                Span& S = sp[j];
+                act[j] = S.cur < S.end;
+                if (act[j] && S.cur >= S.seg_end) {
+                    const uint2 sd = L.seg[S.sg];
+                    const unsigned p0 = L.pref[S.sg];
+                    ++S.sg;
+                    S.seg_end = p0 + sd.y;
+                    S.base = (sd.x & 0x3ffffffu) - p0;              // pair `cur` of the pool is pair base + cur of the tree
+                    const int ow = (int)(sd.x >> 26);
+                    if (ow != S.owner || !S.have) {
+                        S.owner = ow; S.have = true;
+                        const uint4 r0 = L.u.p2.ray[2 * ow], r1 = L.u.p2.ray[2 * ow + 1];
+                        S.q.ox = as_h2(r0.x); S.q.oy = as_h2(r0.y); S.q.oz = as_h2(r0.z); S.q.dx = as_h2(r0.w);
+                        S.q.dy = as_h2(r1.x); S.q.dz = as_h2(r1.y); S.q.a = as_h2(r1.z);
+                    }
                 }
+                // kPP pairs per span and pass, every lane in step (a span that has ended repeats pair 0 and holds nothing).  A clamped
+                // index repeats a pair: the same key twice, harmless.
+                lim[j] = act[j] ? min(S.seg_end, S.end) : 1u;        // > cur
+                const unsigned last = act[j] ? S.base + lim[j] - 1u : 0u;
+                const unsigned i0 = act[j] ? S.base + S.cur : 0u;
+#pragma unroll
+                for (int k = 0; k < kPP; ++k) { ix[j][k] = min(i0 + (unsigned)k, last); e[j][k] = ent[ix[j][k]]; }
             }
-            // kPP pairs per pass, every lane in step (a lane that has finished repeats pair 0 and holds nothing): loads in
-            // flight together, the four discriminants computed side by side, then the rare positives are queued.  A clamped
-            // index repeats a pair: the same key twice, harmless.
-            const unsigned lim = act ? min(seg_end, end) : 1u;       // > cur
-            const unsigned last = act ? base + lim - 1u : 0u;
-            const unsigned i0 = act ? base + cur : 0u;
-            unsigned ix[kPP]; uint4 e[kPP];
+            h2 b[kNS][kPP], d[kNS][kPP], v[kNS][kPP];
+            h2 vm = as_h2(0u);
 #pragma unroll
-            for (int k = 0; k < kPP; ++k) { ix[k] = min(i0 + (unsigned)k, last); e[k] = ent[ix[k]]; }
-#ifdef RT_H16_STATS
-            const unsigned long long tl0 = H16_TICK();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            c_load += H16_TICK() - tl0;
-#endif
-            h2 b[kPP], d[kPP], v[kPP];
+            for (int j = 0; j < kNS; ++j)
 #pragma unroll
-            for (int k = 0; k < kPP; ++k) pair_math(q, e[k], b[k], d[k], v[k]);
-            h2 vm = v[0];
+                for (int k = 0; k < kPP; ++k) { pair_math(sp[j].q, e[j][k], b[j][k], d[j][k], v[j][k]); if (!act[j]) v[j][k] = as_h2(0u); vm = __builtin_elementwise_max(vm, v[j][k]); }
+            if (__ballot((float)vm.x > 0.0f || (float)vm.y > 0.0f) != 0ull) {
 #pragma unroll
-            for (int k = 1; k < kPP; ++k) vm = __builtin_elementwise_max(vm, v[k]);
-#ifdef RT_H16_STATS
-            const unsigned long long tp0 = H16_TICK();
-#endif
-            if (__ballot(act && ((float)vm.x > 0.0f || (float)vm.y > 0.0f)) != 0ull) {
+                for (int j = 0; j < kNS; ++j)
 #pragma unroll
-                for (int k = 0; k < kPP; ++k) {
-                    push_candidates(L, act && (float)v[k].x > 0.0f, b[k].x, d[k].x, ix[k] * 2u + 1u, owner, qn);
-                    push_candidates(L, act && (float)v[k].y > 0.0f, b[k].y, d[k].y, ix[k] * 2u + 2u, owner, qn);
-                }
+                    for (int k = 0; k < kPP; ++k) {
+                        push_candidates(L, (float)v[j][k].x > 0.0f, b[j][k].x, d[j][k].x, ix[j][k] * 2u + 1u, sp[j].owner, qn);
+                        push_candidates(L, (float)v[j][k].y > 0.0f, b[j][k].y, d[j][k].y, ix[j][k] * 2u + 2u, sp[j].owner, qn);
+                    }
             }
-            if (act) cur = min(cur + (unsigned)kPP, lim);
-#ifdef RT_H16_STATS
-            const unsigned long long tp1 = H16_TICK(); c_push += tp1 - tp0;
-#endif
+#pragma unroll
+            for (int j = 0; j < kNS; ++j) if (act[j]) sp[j].cur = min(sp[j].cur + (unsigned)kPP, lim[j]);
             if (qn >= 64u) drain_candidates(L, lane, qn);
-#ifdef RT_H16_STATS
-            c_drain += H16_TICK() - tp1;
-#endif
         }
         drain_candidates(L, lane, qn);
-#ifdef RT_H16_STATS
-        if (lane == 0) { atomicAdd(&g_h16_cyc[4], c_push); atomicAdd(&g_h16_cyc[5], c_drain); atomicAdd(&g_h16_cyc[6], c_load); }
-#endif
         H16_ADD(2, tph);                                             // tests
         // ---- phase 3
         const unsigned long long k = L.key[lane];

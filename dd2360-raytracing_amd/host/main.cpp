@@ -3,8 +3,9 @@
 // Same sequence, same stderr lines, same output modes (0 = PPM to stdout, 1 = none, 3 = output.ppm; mode 2, the
 // OpenGL viewer, is out of scope), same error convention (message + exit code 99), but every step goes through the
 // C-ABI of include/rt_amd.h.  The reference's compile-time knobs become optional trailing arguments:
-//   rt_main [output_mode] [NUM_SPHERES] [nx] [ny] [ns] [USE_OCTREE 0|1] [SPHERES_PER_LEAF] [SPHERE_RADIUS] [USE_FP16 0|1]
-// with the reference's values as defaults (main.cu:22-24, :348-350; acceleration_structure.h:15).
+//   rt_main [output_mode] [NUM_SPHERES] [nx] [ny] [ns] [USE_OCTREE 0|1] [SPHERES_PER_LEAF] [SPHERE_RADIUS] [USE_FP16 0|1] [BUILD_ON_GPU 0|1]
+// with the reference's values as defaults (main.cu:22-24, :348-350; acceleration_structure.h:15).  BUILD_ON_GPU 1 replaces
+// buildOctree + upload (main.cu:405-417) by rt_build_octree_gpu: the same tree, built on the device.
 #include <iostream>
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@ int main(int argc, char** argv) {
     int spheres_per_leaf = 30;           // SPHERES_PER_LEAF
     float sphere_radius = 0.1f;          // SPHERE_RADIUS
     int use_fp16 = 0;                    // USE_FP16
+    int build_on_gpu = 0;
     const int tx = 8, ty = 8;
     if (argc > 1) output_mode = std::stoi(argv[1]);
     if (argc > 2) num_spheres = std::stoi(argv[2]);
@@ -41,6 +43,7 @@ int main(int argc, char** argv) {
     if (argc > 7) spheres_per_leaf = std::stoi(argv[7]);
     if (argc > 8) sphere_radius = std::stof(argv[8]);
     if (argc > 9) use_fp16 = std::stoi(argv[9]);
+    if (argc > 10) build_on_gpu = std::stoi(argv[10]);
     const int precision = use_fp16 ? RT_PRECISION_FP16 : RT_PRECISION_FP32;
 
     std::cerr << "Rendering a " << nx << "x" << ny << " image with " << ns << " samples per pixel ";
@@ -75,7 +78,8 @@ int main(int argc, char** argv) {
     // build octree and upload it
     rt_octree* d_octree = nullptr;
     if (use_octree) {
-        checkHipErrors(rt_build_octree(list.data(), num_spheres, spheres_per_leaf, precision, &d_octree));
+        if (build_on_gpu) checkHipErrors(rt_build_octree_gpu(d_world, spheres_per_leaf, &d_octree, nullptr));
+        else checkHipErrors(rt_build_octree(list.data(), num_spheres, spheres_per_leaf, precision, &d_octree));
         int dropped_full = 0, dropped_outside = 0;
         checkHipErrors(rt_octree_info(d_octree, nullptr, nullptr, nullptr, &dropped_full, &dropped_outside));
         if (dropped_full || dropped_outside)   // the reference prints one line per drop to stdout, corrupting mode 0; here: stderr, once

@@ -459,6 +459,7 @@ def test_arbitrary_world_hit_records_and_frames(rt, cuda, seed, n, spl):
     (["3", "500", "64", "40", "4", "1", "30"], 500, 64, 40, 4, True, 30),
     (["3", "22", "100", "56", "3", "0", "30"], 22, 100, 56, 3, False, 30),
     (["3", "500", "72", "40", "4", "0", "30"], 500, 72, 40, 4, False, 30),           # USE_OCTREE off: the list through the candidate grid
+    (["3", "2000", "64", "40", "4", "1", "30", "0.1", "0", "1"], 2000, 64, 40, 4, True, 30),   # BUILD_ON_GPU: rt_build_octree_gpu instead of buildOctree + upload
 ])
 def test_rt_main_host_program_writes_the_oracle_ppm(rt, cuda, tmp_path, args, n, nx, ny, ns, tree, spl):
     """rt_main (host/main.cpp, the counterpart of the reference's main(), main.cu:347-477) in output mode 3: the
