@@ -94,6 +94,20 @@ def cpu_baseline(cfg, threads, use_octree, rows, spp):
     return samples / dt / 1e6, dt, samples
 
 
+def parse_pmc_dir(d):
+    """{counter: per-dispatch average over the render kernel's dispatches} from the counter_collection CSVs under d"""
+    acc, disp = {}, {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            if "k_render" not in k or "k_render_init" in k:
+                continue
+            c = row["Counter_Name"]
+            acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+            disp.setdefault(c, set()).add(row["Dispatch_Id"])
+    return {c: acc[c] / max(1, len(disp[c])) for c in acc}
+
+
 def collect_pmc(config, list_reference):
     """rocprofv3 --pmc passes over a short run of this same script (child processes, before this process touches the GPU).
     Returns ({counter: per-dispatch average for the render kernel}, note).  Counters come in their own runs, never together
@@ -120,17 +134,7 @@ def collect_pmc(config, list_reference):
             if p.returncode != 0:
                 note = "pmc pass %d failed (rc %d)" % (i, p.returncode)
                 continue
-            acc, disp = {}, {}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    k = row["Kernel_Name"]
-                    if "k_render" not in k or "k_render_init" in k:
-                        continue
-                    c = row["Counter_Name"]
-                    acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
-                    disp.setdefault(c, set()).add(row["Dispatch_Id"])
-            for c in acc:
-                out[c] = acc[c] / max(1, len(disp[c]))
+            out.update(parse_pmc_dir(d))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out, note

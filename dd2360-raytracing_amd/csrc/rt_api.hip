@@ -476,6 +476,7 @@ int rt_free_octree(rt_octree* O) {
         rc = free_all(bufs, 3);
         const int r2 = free_all(O->z->d_acc, 12); if (!rc) rc = r2;
         if (O->z->d_arena) { const hipError_t e = hipFree(O->z->d_arena); if (e != hipSuccess && !rc) rc = (int)e; }
+        delete O->z->host_view;
         delete O->z;
     }
     delete O->host;      // the reference frees a new'ed Octree with free() (main.cu:473); here new/delete match
@@ -484,9 +485,10 @@ int rt_free_octree(rt_octree* O) {
 }
 
 // reference-layout view of a tree built on the device: downloaded when an inspection call first asks for it
-static int ensure_host_view(const rt_octree* O) {
-    if (O->host) return 0;
+static int ensure_host_view(const rt_octree* O, const Octree** view) {
     rt_octree::Lazy& Z = *O->z;
+    if (O->host) { *view = O->host; return 0; }
+    if (Z.host_view) { *view = Z.host_view; return 0; }
     if (!Z.d_ref_nodes) return RT_EINVAL;
     Octree* T = new (std::nothrow) Octree();
     if (!T) return RT_ENOMEM;
@@ -499,7 +501,7 @@ static int ensure_host_view(const rt_octree* O) {
     if (e == hipSuccess) e = hipMemcpy(T->leaf_count.data(), Z.d_leaf_count, sizeof(int32_t) * (size_t)T->leafCount, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(T->leaf_indices.data(), Z.d_leaf_indices, sizeof(int32_t) * (size_t)T->leafCount * T->spl, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete T; return (int)e; }
-    const_cast<rt_octree*>(O)->host = T;          // (the one cached view of a handle that is otherwise read-only here)
+    Z.host_view = T; *view = T;
     return 0;
 }
 
@@ -524,17 +526,19 @@ int rt_octree_info(const rt_octree* O, int* node_count, int* leaf_count, int* sp
 }
 int rt_octree_nodes(const rt_octree* O, rt_octnode* out_nodes) {
     if (!O || !out_nodes) return RT_EINVAL;
-    const int rc = ensure_host_view(O);
+    const Octree* T = nullptr;
+    const int rc = ensure_host_view(O, &T);
     if (rc) return rc;
-    memcpy(out_nodes, O->host->nodes.data(), sizeof(rt_octnode) * RT_OCTREE_MAX_NODES);
+    memcpy(out_nodes, T->nodes.data(), sizeof(rt_octnode) * RT_OCTREE_MAX_NODES);
     return 0;
 }
 int rt_octree_leaves(const rt_octree* O, int32_t* counts, int32_t* indices) {
     if (!O || !counts || !indices) return RT_EINVAL;
-    const int rc = ensure_host_view(O);
+    const Octree* T = nullptr;
+    const int rc = ensure_host_view(O, &T);
     if (rc) return rc;
-    memcpy(counts, O->host->leaf_count.data(), sizeof(int32_t) * O->host->leafCount);
-    memcpy(indices, O->host->leaf_indices.data(), sizeof(int32_t) * (size_t)O->host->leafCount * O->host->spl);
+    memcpy(counts, T->leaf_count.data(), sizeof(int32_t) * T->leafCount);
+    memcpy(indices, T->leaf_indices.data(), sizeof(int32_t) * (size_t)T->leafCount * T->spl);
     return 0;
 }
 

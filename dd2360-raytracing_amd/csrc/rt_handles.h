@@ -63,6 +63,7 @@ struct rt_octree {
         void* d_arena = nullptr;
         const rt_octnode* d_ref_nodes = nullptr; const int32_t* d_leaf_count = nullptr; const int32_t* d_leaf_indices = nullptr;
         int ref_node_count = 0, ref_leaf_count = 0, ref_dropped_full = 0, ref_dropped_outside = 0, ref_spl = 0;
+        Octree* host_view = nullptr;            // ... downloaded here when an inspection call first asks for it
     };
     Lazy* z = nullptr;
     int n_nodes = 0, n_entries = 0;

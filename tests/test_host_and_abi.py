@@ -166,3 +166,26 @@ def test_list_traversal_switch_and_candidate_grid_rules(rt):
     sp["center"][100:140, 0] += 40.0
     near = rt.World(500, 64, 36, spheres=sp, camera=W.camera).list_accel_info()
     assert near["enabled"] and near["large_spheres"] == 43
+
+
+def test_bench_counter_parsing_and_core_count(tmp_path):
+    """bench.py's helpers that do not need a GPU: per-dispatch averages of the render kernel from rocprofv3's counter CSV (other
+    kernels ignored), and a usable-core count of at least one"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = tmp_path / "p0" / "host"
+    d.mkdir(parents=True)
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value",
+            '1,"rt::k_render_init(rt_rand_state*, int)",SQ_INSTS_VALU,5',
+            '2,"void rt::k_render<true, 0, 4>(rt::RenderArgs)",SQ_INSTS_VALU,100',
+            '2,"void rt::k_render<true, 0, 4>(rt::RenderArgs)",SQ_INSTS_VALU,20',      # (one row per XCD / SE: summed per dispatch)
+            '3,"void rt::k_render<true, 0, 4>(rt::RenderArgs)",SQ_INSTS_VALU,140',
+            '3,"void rt::k_render<true, 0, 4>(rt::RenderArgs)",SQ_WAVES,7',
+            '4,"rt::k_tile_order(int const*)",SQ_INSTS_VALU,999']
+    (d / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    got = bench.parse_pmc_dir(str(tmp_path / "p0"))
+    assert got == {"SQ_INSTS_VALU": 130.0, "SQ_WAVES": 7.0}
+    assert bench.usable_cores() >= 1
+    assert set(bench.CONFIGS) == {"c2", "c3", "c4", "c5"} and bench.CONFIGS["c5"]["spp"] == 256
