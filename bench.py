@@ -178,6 +178,7 @@ def main():
     same_gpu = os.environ.get("RT_BENCH_SAME_GPU") == "1"
     if same_gpu:
         local_rank = 0
+    local_rank %= max(1, torch.cuda.device_count())                # fewer devices than ranks: ranks share (RCCL then declines, see below)
     torch.cuda.set_device(local_rank)
     rc, _ = rt.device_check()
     if rc != 0:
@@ -356,6 +357,9 @@ def main():
                                        "calibrated for 16 B/lane streaming reads, this kernel's reads are 24 B-of-48 B strided states and L2-resident scene data "
                                        "(uncalibrated); traffic_fetch_doubled is the upper reading"}
         out["roofline_hbm"]["traffic_fetch_doubled"] = int((2 * fetch_kb + write_kb) * 1024) if traffic is not None else None
+        if traffic is None:
+            out["roofline_hbm"]["note"] = "96 B curandState in+out + vec3 out (12 B, fp16: 6 B) per pixel / kernel time; no counter passes in this run (%s)" % (
+                "N > 1: the PMC passes belong to the one-GPU run" if world > 1 else pmc_note)
         if per_rank is not None:
             out["per_rank_render_ms"] = {"call": [p[0] for p in per_rank], "kernel": [p[1] for p in per_rank],
                                          "note": "device time of each rank's own render_init + render (call) and render kernel, mean over the timed steps"}
