@@ -168,7 +168,6 @@ def main():
 
     import torch
     import rt_amd as rt
-    import rt_dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -189,7 +188,9 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # single node: the control plane stays on the loopback
         dist.init_process_group("gloo")
 
-    nx, ny = rt_dist.scaled_frame(cfg["nx"], cfg["ny"], world) if weak else (cfg["nx"], cfg["ny"])
+    nx, ny = cfg["nx"], cfg["ny"]
+    if weak:                                                       # same aspect, ~world times the pixels
+        nx, ny = int(round(nx * world ** 0.5)), int(round(ny * world ** 0.5))
     spp = cfg["spp"]
     precision = rt.FP16 if cfg.get("fp16") else rt.FP32
 

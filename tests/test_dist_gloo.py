@@ -1,7 +1,8 @@
-"""N>1 path on CPU (not gpu): two gloo ranks split a frame by the round-robin tile rule, gather the compact part
-buffers with the same rt_dist.gather_parts call bench.py uses over RCCL, and rank 0 reassembles the frame.
-The renderer is replaced by a pixel-id fill (the render itself needs a GPU); a numpy restatement of rt_assemble's
-index arithmetic (tests only) checks that every pixel of the frame arrives exactly once at the right place."""
+"""N>1 path on CPU (not gpu): two gloo ranks split a frame by rt_multi_render's round-robin tile rule, gather the compact
+part buffers (equal padded sizes, one gather to rank 0 — the layout rt_multi_render's staging slots have) and rank 0 reassembles
+the frame.  The renderer is replaced by a pixel-id fill (the render itself needs a GPU: tests/test_gpu_multi.py runs the real
+rt_multi_render with 2 and 3 ranks); a numpy restatement of rt_assemble's index arithmetic (tests only) checks that every pixel
+of the frame arrives exactly once at the right place, and the partition arithmetic is checked against rt_part_pixels."""
 import os
 import socket
 import sys
@@ -11,6 +12,19 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
+
+
+def part_pixels(nx, ny, part, nparts):
+    """element count of the compact buffer of one part (what rt_part_pixels returns)"""
+    if nparts == 1:
+        return nx * ny
+    tx, ty = (nx + 7) // 8, (ny + 7) // 8
+    return (tx * ty - part + nparts - 1) // nparts * 64
+
+
+def padded_part_pixels(nx, ny, nparts):
+    """the staging slot size: part 0 is the largest"""
+    return part_pixels(nx, ny, 0, nparts)
 
 
 def local_pixel_ids(nx, ny, part, nparts, padded):
@@ -43,16 +57,16 @@ def assemble_numpy(parts, nx, ny, nparts, per):
 def _worker(rank, world, port, nx, ny, q):
     import torch
     import torch.distributed as dist
-    import rt_dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        per = rt_dist.padded_part_pixels(nx, ny, world)
-        mine = rt_dist.part_pixels(nx, ny, rank, world)
+        per = padded_part_pixels(nx, ny, world)
+        mine = part_pixels(nx, ny, rank, world)
         ids = local_pixel_ids(nx, ny, rank, world, per)
         assert (ids[mine:] == -1).all()
         send = torch.from_numpy(ids.astype(np.float64))
-        got = rt_dist.gather_parts(dist, send, rank, world, dst=0)
+        got = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, got, dst=0)
         ok = True
         if rank == 0:
             parts = torch.cat(got).numpy().astype(np.int64)
@@ -86,16 +100,10 @@ def test_two_rank_tile_split_gather_assemble(nx, ny):
 
 
 def test_partition_sizes_match_library(rt):
-    import rt_dist
-    for nx, ny in ((1200, 800), (61, 35), (3394, 2263)):
-        for nparts in (1, 2, 4, 8):
-            for p in range(nparts):
-                assert rt_dist.part_pixels(nx, ny, p, nparts) == rt.part_pixels(nx, ny, rt.Partition(p, nparts))
-            assert rt_dist.padded_part_pixels(nx, ny, nparts) == rt.part_pixels(nx, ny, rt.Partition(0, nparts))
-
-
-def test_scaled_frame_keeps_pixels_per_gpu():
-    import rt_dist
-    for n in (1, 2, 4, 8):
-        nx, ny = rt_dist.scaled_frame(1200, 800, n)
-        assert abs(nx * ny / (n * 960000) - 1) < 0.002 and abs(nx / ny - 1.5) < 0.002
+    for nx, ny in ((1200, 800), (61, 35), (3840, 2160)):
+        for nparts in (1, 2, 3, 4, 8):
+            sizes = [rt.part_pixels(nx, ny, rt.Partition(p, nparts)) for p in range(nparts)]
+            assert sizes == [part_pixels(nx, ny, p, nparts) for p in range(nparts)]
+            assert max(sizes) == sizes[0] == padded_part_pixels(nx, ny, nparts)
+            tiles = ((nx + 7) // 8) * ((ny + 7) // 8)
+            assert sum(sizes) == (tiles * 64 if nparts > 1 else nx * ny)
