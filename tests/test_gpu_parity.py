@@ -582,3 +582,48 @@ def test_c5_geometry_rows_against_the_oracle(rt, cuda):
     for row in (40, 700, 1100, 2100):
         ref, _ = S.render(ns, row0=row, rows=1, nthreads=8)
         assert np.array_equal(bits(got[row]), bits(ref[0])), "row %d differs" % row
+
+
+def to_half_image(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,n,spl", [(21, 400, 30), (22, 5000, 48), (23, 12000, 64)])
+def test_fp16_arbitrary_world_hit_records_and_frames(rt, cuda, seed, n, spl):
+    """USE_FP16 on worlds the caller builds itself (large spheres stored in dozens of cells: a wave's rays visit more bucket
+    ranges than its pool of segments holds, so the scan runs in several rounds; ghosts; spheres outside the root box): hit
+    records of the redistributed binary16 scan and a small frame equal the fp16 oracle."""
+    torch = cuda
+    nx, ny, ns = 64, 40, 3
+    sp, _ = random_world(rt, seed, n, nx, ny, big=24)
+    for f in ("center", "radius", "albedo", "param"):
+        sp[f] = to_half_image(sp[f])
+    sp[0] = ((0.0, -1000.0, -1.0), 1000.0, rt.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)
+    rng = np.random.default_rng(seed)
+    cam = rt.camera_init((rng.uniform(8, 14), rng.uniform(1, 4), rng.uniform(-4, 4)), (0, 0.3, 0), (0, 1, 0), 35.0,
+                         float(np.float16(nx) / np.float16(ny)), 0.05, 10.0, precision=rt.FP16)
+    W = rt.World(n, nx, ny, precision=rt.FP16, spheres=sp, camera=cam)
+    O = rt.Octree(W, spl)
+    geom = np.concatenate([sp["center"], sp["radius"][:, None]], 1)
+    mat = np.concatenate([sp["albedo"], sp["param"][:, None]], 1)
+    S = OracleScene(n, nx, ny, fp16=True, use_octree=True, spl=spl, custom=(geom, mat, sp["material"], cam.view(np.float32).ravel()))
+    nrays = 40_000 if n < 5000 else 12_000                      # (the binary16 oracle is ~30x slower than the fp32 one)
+    rays = to_half_image(random_rays(nrays, 900 + seed))
+    d_rays = torch.from_numpy(rays).cuda()
+    for tree in (True, False):
+        d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+        rt.trace_rays(W, O if tree else None, d_rays, nrays, d_out)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(rt.hit_record_dtype)
+        ref = S.trace(rays, mode=2 if tree else 1)
+        assert np.array_equal(got["sphere"], ref["sphere"]), tree
+        assert np.array_equal(bits(got["t"]), bits(ref["t"])), tree
+        assert np.array_equal(bits(got["normal"]), bits(ref["normal"])), tree
+    st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny, precision=rt.FP16)
+    rt.render_init(nx, ny, st); rt.render(fb, nx, ny, ns, W, st, O)
+    torch.cuda.synchronize()
+    ref, ref_st = S.render(ns, nthreads=8)
+    got = half_bits(fb).reshape(ny, nx, 3)
+    nan = np.isnan(ref)
+    assert np.array_equal(got[~nan], f32_to_half_bits(ref)[~nan])
+    assert np.array_equal(st.cpu().numpy().view(np.uint32).reshape(-1, 12)[:, :6], ref_st[:, :6])
