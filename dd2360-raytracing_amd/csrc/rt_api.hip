@@ -10,6 +10,7 @@
 #include <limits>
 #include <algorithm>
 #include "rt_handles.h"
+#include "rt_octgeom.h"
 
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
@@ -386,13 +387,16 @@ static int octree_upload(const rt_octree* O) {
         // plane table: the distinct box coordinates per axis, and per node its six indices into the concatenated table
         std::vector<float> planes; int np[3] = {0, 0, 0};
         {
+            // the tree's boxes are the root box halved three times: 9 planes per axis, whichever nodes exist (rt_octgeom.h)
+            static float fbox[kFullNodes][6];
+            full_tree_boxes<half_t>(fbox);
             std::vector<float> ax[3];
-            for (const DevNode& d : hn) { const float b[6] = {d.lo[0], d.lo[1], d.lo[2], d.hix, d.hiy, d.hiz}; for (int k = 0; k < 3; ++k) { ax[k].push_back(b[k]); ax[k].push_back(b[3 + k]); } }
+            for (int fr = 0; fr < kFullNodes; ++fr) for (int k = 0; k < 3; ++k) { ax[k].push_back(fbox[fr][k]); ax[k].push_back(fbox[fr][3 + k]); }
             bool ok = true;
-            for (int k = 0; k < 3; ++k) {
-                std::sort(ax[k].begin(), ax[k].end());
-                ax[k].erase(std::unique(ax[k].begin(), ax[k].end()), ax[k].end());
-                for (float v : ax[k]) if (!(v == v)) ok = false;
+            for (int k = 0; k < 3; ++k) { std::sort(ax[k].begin(), ax[k].end()); ax[k].erase(std::unique(ax[k].begin(), ax[k].end()), ax[k].end()); }
+            for (const DevNode& d : hn) {                                // (a tree from elsewhere: every node box must lie on those planes)
+                const float bx[6] = {d.lo[0], d.lo[1], d.lo[2], d.hix, d.hiy, d.hiz};
+                for (int q = 0; q < 6 && ok; ++q) ok = std::binary_search(ax[q % 3].begin(), ax[q % 3].end(), bx[q]);
             }
             if (ok && ax[0].size() + ax[1].size() + ax[2].size() <= 30) {
                 int off[3] = {0, (int)ax[0].size(), (int)(ax[0].size() + ax[1].size())};
@@ -546,10 +550,18 @@ int rt_octree_leaves(const rt_octree* O, int32_t* counts, int32_t* indices) {
 // 0 nodes, 1 ent_hot, 2 ent_id, 3 large_hot, 4 large_brick, 5 cs, 6 hot, 7 brick, 8 memb_start, 9 memb_cell, 10 cellnode,
 // 11 bits_index, 12 cellbits.  *bytes receives the array's size; the copy happens when cap suffices.
 int rt_octree_debug_array(const rt_octree* O, int which, void* out, size_t cap, size_t* bytes) {
-    if (!O || !bytes || O->precision != RT_PRECISION_FP32) return RT_EINVAL;
+    if (!O || !bytes) return RT_EINVAL;
+    if (O->precision != RT_PRECISION_FP32 && which > 2) return RT_EINVAL;      // a binary16 tree has no candidate grid
     const int rc = octree_upload(O);
     if (rc) return rc;
     const rt_octree::Lazy& Z = *O->z;
+    if (O->precision == RT_PRECISION_FP16) {                                   // pair layout: 16 B per pair, two table entries per pair
+        const void* src16 = which == 0 ? (const void*)Z.dev.nodes4 : which == 1 ? (const void*)Z.dev.ent_hot : (const void*)Z.dev.ent_id;
+        const size_t sz16 = which == 0 ? (size_t)Z.dev.n_nodes * sizeof(DevNode) : which == 1 ? (size_t)(Z.dev.n_entries / 2) * 16 : (size_t)Z.dev.n_entries * 4;
+        *bytes = sz16;
+        if (!out || cap < sz16 || sz16 == 0) return 0;
+        return (int)hipMemcpy(out, src16, sz16, hipMemcpyDeviceToHost);
+    }
     const DevAccel& p = Z.dev.acc;
     const size_t total = O->accel.n_entries, ncell = (size_t)O->accel.p.G * O->accel.p.G, nl = (size_t)O->accel.p.n_large;
     const void* src = nullptr; size_t sz = 0;
@@ -575,18 +587,18 @@ int rt_octree_debug_array(const rt_octree* O, int which, void* out, size_t cap, 
 }
 
 // buildOctree + traversal copy + candidate grid on the device, from the world's device-resident sphere list (rt_build.hip).
-// Binary16 worlds, and inputs the device build declines, are built on the host from the world's own copy of the list.
+// Inputs the device build declines are built on the host from the world's own copy of the list.
 int rt_build_octree_gpu(const rt_world* world, int spheres_per_leaf, rt_octree** out, void* stream) {
     if (!world || !out || spheres_per_leaf <= 0) return RT_EINVAL;
     *out = nullptr;
-    if (world->precision == RT_PRECISION_FP32) {
+    {
         int rc = world_upload(world);
         if (rc) return rc;
         rt_octree* O = new (std::nothrow) rt_octree();
         if (!O) return RT_ENOMEM;
         O->z = new (std::nothrow) rt_octree::Lazy();
         if (!O->z) { delete O; return RT_ENOMEM; }
-        O->precision = RT_PRECISION_FP32;
+        O->precision = world->precision;
         rc = gpubuild::build(O, (const float4*)world->z->d_geom, (const int32_t*)world->z->d_kind, world->n, spheres_per_leaf, (hipStream_t)stream);
         if (rc == 0) { *out = O; return 0; }
         (void)rt_free_octree(O);

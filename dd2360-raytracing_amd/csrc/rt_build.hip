@@ -15,7 +15,8 @@
 // per-sphere or per-cell work plus radix sorts (rocPRIM).  The host supplies a handful of scalars on the way (four small
 // read-backs): sizes of the arrays to allocate, the grid's cell size from the median radius.
 //
-// FP32 trees only: binary16 trees (USE_FP16) keep the host build.
+// Binary16 trees (USE_FP16): the same reference layout in real_t = binary16 arithmetic, then the pair layout and plane table the
+// binary16 kernels read, and no candidate grid.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -51,12 +52,18 @@ inline double double_of(unsigned long long o) {
 
 // ---------------------------------------------------------------------------------------------- the reference-layout tree
 // insert() for every sphere at once: which nodes it reaches, which level-3 cells it lands in
+template <class R>
 __global__ __launch_bounds__(256) void k_pairs(const float4* __restrict__ geom, int n, const float (*__restrict__ box)[6], unsigned* first,
                                                unsigned long long* pairs, unsigned cap, Counters* C) {
     const int i = blockIdx.x * 256 + threadIdx.x + 1;                 // the ground sphere (index 0) is not in the tree (:208)
     if (i >= n) return;
     const float4 g = geom[i];
-    auto touches = [&](int fr) { return sphere_touches_box<float>(g.x, g.y, g.z, g.w, box[fr], box[fr] + 3); };
+    const R cx = real_from<R>(g.x), cy = real_from<R>(g.y), cz = real_from<R>(g.z), rad = real_from<R>(g.w);
+    auto touches = [&](int fr) {
+        const R lo[3] = {real_from<R>(box[fr][0]), real_from<R>(box[fr][1]), real_from<R>(box[fr][2])};
+        const R hi[3] = {real_from<R>(box[fr][3]), real_from<R>(box[fr][4]), real_from<R>(box[fr][5])};
+        return sphere_touches_box<R>(cx, cy, cz, rad, lo, hi);
+    };
     if (!touches(0)) { atomicAdd(&C->dropped_outside, 1u); return; }
     for (int a = 0; a < 8; ++a) {
         const int f1 = 1 + 73 * a;
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(64) void k_leaves(const unsigned* __restrict__ seg_
 // OctNode array in the reference's numbering, and the pre-order traversal copy with skip links (one block)
 __global__ __launch_bounds__(1024) void k_nodes(const float (*__restrict__ box)[6], const int* __restrict__ node_id, const int* __restrict__ dev_index, const int* __restrict__ accepted,
                                                 const int* __restrict__ leaf_of, const int* __restrict__ hit_cnt, int spl, rt_octnode* ref_nodes, DevNode* dnodes,
-                                                int* ent_first, int32_t* devcell, int32_t* cellnode, Counters* C) {
+                                                int* ent_first, int32_t* devcell, int32_t* cellnode, int* dev_to_fr, Counters* C) {
     __shared__ int s_ex[kFullNodes + 1];         // existing nodes before fr
     __shared__ int s_ef[kFullNodes + 1];         // hittable entries before fr
     const int t = threadIdx.x;
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(1024) void k_nodes(const float (*__restrict__ box)[
         d.skip = s_ex[fr + full_subtree(level)];
         d.first = s_ef[fr]; d.count = level == 3 ? hit_cnt[fr] : 0; d.ref_index = id;
         dnodes[k] = d;
+        dev_to_fr[k] = fr;
         rt_octnode rn; rn.level = level;
         for (int q = 0; q < 6; ++q) rn.aabb[q] = box[fr][q];
         for (int o = 0; o < 8; ++o) {
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(1024) void k_nodes(const float (*__restrict__ box)[
 }
 
 // bucket contents in traversal order (ghost entries removed), and (sphere, node) pairs for the membership lists
+template <class R>
 __global__ __launch_bounds__(64) void k_entries(const unsigned* __restrict__ seg_start, const int* __restrict__ accepted, const int* __restrict__ dev_index, const int* __restrict__ ent_first,
                                                 const unsigned long long* __restrict__ sorted, const float4* __restrict__ geom, const int32_t* __restrict__ kind,
                                                 float4* ent_hot, int32_t* ent_id, unsigned long long* pair2, float4* hot_of) {
@@ -218,12 +227,56 @@ __global__ __launch_bounds__(64) void k_entries(const unsigned* __restrict__ seg
         if (keep) {
             const int pos = base + __popcll(m & lt);
             const float4 g = geom[s];
-            const float4 h = make_float4(g.x, g.y, g.z, g.w * g.w);          // radius*radius in float (sphere.h:21)
+            const R rr = real_from<R>(g.w);
+            const float4 h = make_float4(g.x, g.y, g.z, as_float(rr * rr));  // radius*radius in real_t (sphere.h:21)
             ent_id[pos] = s; ent_hot[pos] = h; hot_of[s] = h;
             pair2[pos] = ((unsigned long long)(unsigned)s << 32) | (unsigned)k;
         }
         base += __popcll(m);
     }
+}
+
+// ---------------------------------------------------------------------------------------------- USE_FP16 traversal copy
+// The binary16 kernels read the bucket entries as PAIRS (rt_kernels_fp16.hip; the layout rt_octree_upload derives on the host):
+// node first/count in pairs, an odd count padded with a NaN sphere, the entry -> sphere table following the pairs, and per node
+// the six indices of its box planes in the tree's plane table (x planes 0..8, y 9..17, z 18..26: the root box halved 3 times).
+__global__ void k_pair_offsets(DevNode* dnodes, int n_nodes, const int* __restrict__ dev_to_fr, int* pair_first, Counters* C) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int run = 0;
+    for (int k = 0; k < n_nodes; ++k) {
+        pair_first[k] = run;
+        run += (dnodes[k].count + 1) / 2;
+        int level, a, b, c; full_path(dev_to_fr[k], level, a, b, c);
+        const int sh = 3 - level;                                      // a level-L node spans 2^(3-L) level-3 cells per axis
+        uint32_t w = 0;
+        for (int axis = 0; axis < 3; ++axis) {
+            const int bit = 2 - axis;                                  // octant bit 2 = x, 1 = y, 0 = z
+            const int cell = level == 0 ? 0 : level == 1 ? ((a >> bit) & 1) : level == 2 ? ((((a >> bit) & 1) << 1) | ((b >> bit) & 1)) : cell_coord(a, b, c, bit);
+            const int lo = (cell << sh) + 9 * axis, hi = ((cell + 1) << sh) + 9 * axis;
+            w |= (uint32_t)lo << (10 * axis); w |= (uint32_t)hi << (10 * axis + 5);
+        }
+        dnodes[k].pad[0] = (int32_t)w;
+    }
+    C->reg_total = (unsigned)(2 * run);                               // entry slots of the pair layout (n_entries stays the entry count)
+}
+__global__ __launch_bounds__(64) void k_pair_fill(DevNode* dnodes, const int* __restrict__ pair_first, const float4* __restrict__ ent_hot, const int32_t* __restrict__ ent_id,
+                                                  uint4* pairs, int32_t* pid) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int first = dnodes[k].first, cnt = dnodes[k].count, pf = pair_first[k];
+    auto hb = [](float v) { return (uint32_t)half_t(v).bits; };
+    for (int e = 2 * lane; e < cnt; e += 128) {
+        const float4 A = ent_hot[first + e];
+        const bool two = e + 1 < cnt;
+        const float4 B = two ? ent_hot[first + e + 1] : A;
+        const uint32_t nanb = 0x7e00u;
+        const int p = pf + e / 2;
+        pairs[p] = make_uint4(hb(A.x) | ((two ? hb(B.x) : nanb) << 16), hb(A.y) | ((two ? hb(B.y) : nanb) << 16),
+                              hb(A.z) | ((two ? hb(B.z) : nanb) << 16), hb(A.w) | ((two ? hb(B.w) : nanb) << 16));
+        pid[2 * p] = ent_id[first + e];
+        pid[2 * p + 1] = two ? ent_id[first + e + 1] : -1;
+    }
+    __syncthreads();
+    if (lane == 0) { dnodes[k].first = pf; dnodes[k].count = (cnt + 1) / 2; }
 }
 
 // ---------------------------------------------------------------------------------------------- candidate grid (rt_accel.h)
@@ -374,11 +427,11 @@ static int excl_scan(int* in, int* out, size_t n, void* temp, size_t temp_bytes,
 }
 static unsigned bits_for(unsigned long long v) { unsigned b = 1; while (b < 64 && (v >> b)) ++b; return b; }
 
-static const float (*device_boxes(int* rc))[6] {                      // the 585 boxes, uploaded once per process
+template <class R> static const float (*device_boxes(int* rc))[6] {   // the 585 boxes (float images of real_t), uploaded once per process
     static float (*d_box)[6] = nullptr;
     if (!d_box) {
         static float h_box[kFullNodes][6];
-        full_tree_boxes<float>(h_box);
+        full_tree_boxes<R>(h_box);
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, sizeof(h_box));
         if (e == hipSuccess) e = hipMemcpy(p, h_box, sizeof(h_box), hipMemcpyHostToDevice);
@@ -392,7 +445,8 @@ static const float (*device_boxes(int* rc))[6] {                      // the 585
 // device build cannot take this input (the caller then builds on the host).
 int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int spl, hipStream_t st) {
     int rc = 0;
-    const float (*d_box)[6] = device_boxes(&rc);
+    const bool fp16 = O->precision == RT_PRECISION_FP16;
+    const float (*d_box)[6] = fp16 ? device_boxes<half_t>(&rc) : device_boxes<float>(&rc);
     if (!d_box) return rc;
     rt_octree::Lazy& Z = *O->z;
     // ---- workspace: everything whose size is known from n (freed at the end)
@@ -425,7 +479,10 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     RT_TRY(hipMemsetAsync(leaf_of, 0, sizeof(int) * kFullNodes * 8, st));
     RT_TRY(hipMemsetAsync(hot_of, 0, sizeof(float4) * (size_t)n, st));
     // ---- the reference-layout tree
-    if (n > 1) hipLaunchKernelGGL(k_pairs, dim3(blocks_for((size_t)n - 1)), dim3(256), 0, st, d_geom, n, d_box, first, pairs_a, (unsigned)cap, C);
+    if (n > 1) {
+        if (fp16) hipLaunchKernelGGL(k_pairs<half_t>, dim3(blocks_for((size_t)n - 1)), dim3(256), 0, st, d_geom, n, d_box, first, pairs_a, (unsigned)cap, C);
+        else hipLaunchKernelGGL(k_pairs<float>, dim3(blocks_for((size_t)n - 1)), dim3(256), 0, st, d_geom, n, d_box, first, pairs_a, (unsigned)cap, C);
+    }
     RT_TRY(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
     RT_TRY(hipStreamSynchronize(st));                                   // (1) how many pairs to sort
     if (hc.pair_overflow) return RT_ENOTSUP;
@@ -443,7 +500,8 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     // ---- first part of the tree's own allocation: reference layout + traversal copy (entries bounded by the pairs)
     const size_t ent_cap = n_pairs ? n_pairs : 1;
     size_t a_bytes = sizeof(rt_octnode) * RT_OCTREE_MAX_NODES + sizeof(int32_t) * (size_t)leaf_count * (1 + (size_t)spl) + sizeof(DevNode) * (size_t)node_count
-                   + ent_cap * (16 + 4 + 4 + 8 + 8) + (size_t)n * (4 + 4 + 4) + 512 * 4 + (size_t)node_count * 4 + 64 * 256;
+                   + ent_cap * (16 + 4 + 4 + 8 + 8) + (size_t)n * (4 + 4 + 4) + 512 * 4 + (size_t)node_count * 4 + 64 * 256
+                   + (fp16 ? (ent_cap / 2 + (size_t)node_count + 1) * (16 + 8) + (size_t)node_count * 8 + 27 * 4 + 8 * 256 : 0);
     void* a_mem = nullptr;
     RT_TRY(hipMalloc(&a_mem, a_bytes));
     Z.d_arena = a_mem;                                                  // owned by the handle from here on (rt_free_octree)
@@ -455,6 +513,10 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     int32_t* memb_cell = A.take<int32_t>(ent_cap); int32_t* memb_start = A.take<int32_t>((size_t)n + 1);
     int32_t* bits_index = A.take<int32_t>(n); int32_t* cellnode = A.take<int32_t>(512); int32_t* devcell = A.take<int32_t>(node_count);
     unsigned long long* pair2a = A.take<unsigned long long>(ent_cap); unsigned long long* pair2b = A.take<unsigned long long>(ent_cap);
+    int* dev_to_fr = A.take<int>(node_count);
+    const size_t pair_cap = ent_cap / 2 + (size_t)node_count + 1;       // binary16 only: every node may add a padding half-pair
+    uint4* h_pairs = fp16 ? A.take<uint4>(pair_cap) : nullptr; int32_t* h_pid = fp16 ? A.take<int32_t>(2 * pair_cap) : nullptr;
+    int* pair_first = fp16 ? A.take<int>(node_count) : nullptr; float* d_planes = fp16 ? A.take<float>(27) : nullptr;
     if (A.used > A.size) return RT_ENOMEM;
     RT_TRY(hipMemsetAsync(ref_nodes, 0, sizeof(rt_octnode) * RT_OCTREE_MAX_NODES, st));
     RT_TRY(hipMemsetAsync(leaf_cnt, 0, sizeof(int32_t) * (size_t)leaf_count, st));
@@ -463,9 +525,40 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     hipLaunchKernelGGL(k_leaves, dim3(kFullNodes), dim3(64), 0, st, (const unsigned*)seg_start, (const int*)accepted, (const int*)leaf_of, (const unsigned long long*)pairs_b, d_kind, spl,
                        leaf_cnt, leaf_idx, hit_cnt);
     hipLaunchKernelGGL(k_nodes, dim3(1), dim3(1024), 0, st, d_box, (const int*)node_id, (const int*)dev_index, (const int*)accepted, (const int*)leaf_of, (const int*)hit_cnt, spl,
-                       ref_nodes, dnodes, ent_first, devcell, cellnode, C);
-    hipLaunchKernelGGL(k_entries, dim3(kFullNodes), dim3(64), 0, st, (const unsigned*)seg_start, (const int*)accepted, (const int*)dev_index, (const int*)ent_first,
-                       (const unsigned long long*)pairs_b, d_geom, d_kind, ent_hot, ent_id, pair2a, hot_of);
+                       ref_nodes, dnodes, ent_first, devcell, cellnode, dev_to_fr, C);
+    if (fp16) hipLaunchKernelGGL(k_entries<half_t>, dim3(kFullNodes), dim3(64), 0, st, (const unsigned*)seg_start, (const int*)accepted, (const int*)dev_index, (const int*)ent_first,
+                                 (const unsigned long long*)pairs_b, d_geom, d_kind, ent_hot, ent_id, pair2a, hot_of);
+    else hipLaunchKernelGGL(k_entries<float>, dim3(kFullNodes), dim3(64), 0, st, (const unsigned*)seg_start, (const int*)accepted, (const int*)dev_index, (const int*)ent_first,
+                            (const unsigned long long*)pairs_b, d_geom, d_kind, ent_hot, ent_id, pair2a, hot_of);
+    if (fp16) {
+        // the binary16 kernels' layout: pairs, pair-based node ranges, plane table; no candidate grid (its error bounds are binary32 bounds)
+        float h_box[kFullNodes][6];
+        full_tree_boxes<half_t>(h_box);
+        float planes[27];
+        for (int axis = 0; axis < 3; ++axis) {                          // the 9 planes per axis, ascending: the low faces of the 8 level-3 cells + the root's high face
+            for (int c = 0; c < 8; ++c) {
+                const int bit = 2 - axis;
+                const int a = ((c >> 2) & 1) << bit, b = ((c >> 1) & 1) << bit, cc = (c & 1) << bit;
+                planes[9 * axis + c] = h_box[full_rank(3, a, b, cc)][axis];
+            }
+            planes[9 * axis + 8] = h_box[0][3 + axis];
+        }
+        RT_TRY(hipMemcpyAsync(d_planes, planes, sizeof(planes), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, st, dnodes, node_count, (const int*)dev_to_fr, pair_first, C);
+        hipLaunchKernelGGL(k_pair_fill, dim3(node_count), dim3(64), 0, st, dnodes, (const int*)pair_first, (const float4*)ent_hot, (const int32_t*)ent_id, h_pairs, h_pid);
+        RT_TRY(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
+        RT_TRY(hipStreamSynchronize(st));
+        RT_TRY(hipGetLastError());
+        O->n_nodes = node_count; O->n_entries = (int)hc.n_entries; O->n_world = n;
+        Z.dev.n_nodes = node_count; Z.dev.n_entries = (int)hc.reg_total;
+        Z.dev.nodes4 = (const float4*)dnodes; Z.dev.ent_hot = (const float4*)h_pairs; Z.dev.ent_id = h_pid;
+        Z.dev.h16_planes = d_planes; Z.dev.h16_np[0] = Z.dev.h16_np[1] = Z.dev.h16_np[2] = 9;
+        Z.d_ref_nodes = ref_nodes; Z.d_leaf_count = leaf_cnt; Z.d_leaf_indices = leaf_idx;
+        Z.ref_node_count = node_count; Z.ref_leaf_count = leaf_count; Z.ref_dropped_full = (int)hc.dropped_full; Z.ref_dropped_outside = (int)hc.dropped_outside; Z.ref_spl = spl;
+        DevAccel off{}; O->accel.p = off; O->accel.n_entries = 0; Z.dev.acc = off;
+        Z.uploaded = true;
+        return 0;
+    }
     RT_TRY(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
     RT_TRY(hipStreamSynchronize(st));                                   // (3) number of bucket entries
     const int n_entries = (int)hc.n_entries;

@@ -144,9 +144,10 @@ int rt_octree_upload(rt_octree* octree);   /* the cudaMalloc + cudaMemcpy of mai
  * traversal copy and candidate grid, array for array and bit for bit — built from the world's device-resident sphere list
  * (uploads the world if need be) by per-sphere / per-cell kernels and radix sorts; ready to render when the call returns
  * (it synchronises with `stream` a few times: array sizes come back from the device).  N = 100 000, SPHERES_PER_LEAF 320:
- * 1.9 ms instead of 25.6 ms of host build + 3 ms of upload (MI355X box).  USE_FP16 worlds are built on the host. */
+ * 1.9 ms instead of 25.6 ms of host build + 3 ms of upload (MI355X box).  USE_FP16 worlds: the tree in binary16 arithmetic, the pair
+ * layout and plane table of the binary16 kernels, no candidate grid — again what rt_build_octree + rt_octree_upload give. */
 int rt_build_octree_gpu(const rt_world* world, int spheres_per_leaf, rt_octree** out, void* stream);
-/* one device-resident array of an FP32 tree, copied to the host (parity checks of the two builds): 0 traversal nodes, 1 bucket
+/* one device-resident array of a tree, copied to the host (parity checks of the two builds; binary16 trees: 0-2 only): 0 traversal nodes, 1 bucket
  * entries (c, r^2), 2 entry -> sphere, 3/4 large spheres + bricks, 5 grid cell starts, 6/7 grid entries + bricks, 8/9 membership
  * lists, 10 cell -> node, 11/12 membership bitmaps.  *bytes = size of the array; copied when cap suffices. */
 int rt_octree_debug_array(const rt_octree* octree, int which, void* out, size_t cap, size_t* bytes);

@@ -63,8 +63,34 @@ def test_frames_through_a_device_built_tree(rt, cuda):
         assert torch.equal(fb.view(torch.int32), out[0][0].view(torch.int32)) and torch.equal(st, out[0][1])
 
 
-def test_device_build_of_a_binary16_world_falls_back_to_the_host(rt, cuda):
-    W = rt.World(500, 64, 40, precision=rt.FP16).upload()
-    G = rt.Octree(W, 30, gpu=True)
-    H = rt.Octree(W, 30)
-    assert G.info() == H.info() and np.array_equal(G.nodes().view(np.uint8), H.nodes().view(np.uint8))
+@pytest.mark.parametrize("n,spl,custom", [(500, 30, False), (10000, 32, False), (2000, 3, False), (3000, 40, True)])
+def test_device_build_of_binary16_trees(rt, cuda, n, spl, custom):
+    """USE_FP16: the reference layout in binary16 arithmetic, the pair layout of the bucket entries, pair-based node ranges and
+    plane indices equal the host build's; frames through both are the same"""
+    torch = cuda
+    nx, ny, ns = 96, 56, 3
+    if custom:
+        sp, _ = random_world(rt, 31, n, nx, ny, big=12)
+        for f in ("center", "radius", "albedo", "param"):
+            sp[f] = np.asarray(sp[f], np.float32).astype(np.float16).astype(np.float32)
+        sp[0] = ((0.0, -1000.0, -1.0), 1000.0, rt.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)
+        cam = rt.camera_init((12, 2, 3), (0, 0.3, 0), (0, 1, 0), 35.0, float(np.float16(nx) / np.float16(ny)), 0.05, 10.0, precision=rt.FP16)
+        W = rt.World(n, nx, ny, precision=rt.FP16, spheres=sp, camera=cam).upload()
+    else:
+        W = rt.World(n, nx, ny, precision=rt.FP16).upload()
+    H = rt.Octree(W, spl).upload()
+    G = rt.Octree(W, spl, gpu=True)
+    assert H.info() == G.info()
+    assert np.array_equal(H.nodes().view(np.uint8), G.nodes().view(np.uint8))
+    hc, hi = H.leaves(); gc, gi = G.leaves()
+    assert np.array_equal(hc, gc) and np.array_equal(hi, gi)
+    for k in range(3):                                            # traversal nodes (pair ranges, plane indices), pairs, pair -> sphere
+        a, b = H.device_array(k), G.device_array(k)
+        assert a.size == b.size and np.array_equal(a, b), k
+    out = []
+    for O in (H, G):
+        st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny, precision=rt.FP16)
+        rt.render_init(nx, ny, st); rt.render(fb, nx, ny, ns, W, st, O)
+        torch.cuda.synchronize()
+        out.append((fb, st))
+    assert torch.equal(out[0][0].view(torch.int16), out[1][0].view(torch.int16)) and torch.equal(out[0][1], out[1][1])
