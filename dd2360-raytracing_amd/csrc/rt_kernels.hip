@@ -31,8 +31,11 @@ namespace rt {
 #define RT_DEV static __device__ __forceinline__
 
 // minimum waves per SIMD the render kernel is compiled for (register budget 512/RT_RENDER_WAVES VGPRs per lane)
+#ifndef RT_COOP_SPARSE
+#define RT_COOP_SPARSE 0       // cooperative single-ray walks in the pooled variant for waves with <= this many walkers (1, 2: within the run-to-run noise of 0)
+#endif
 #ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 3
+#define RT_RENDER_WAVES 4
 #endif
 // grid entries tested per walk step (loads in flight together): on sparse grids (C3: 3.6 entries per cell; the kernel variant
 // with grouped cooperative walks) / on dense grids (C5: 37 per cell; the plain variant).  Measured: C3 4: 22.9 ms, 6: 22.7, 8: 23.5;
@@ -66,7 +69,7 @@ namespace rt {
 #define RT_MED_RATE 12
 #endif
 #ifndef RT_COOP_MAX
-#define RT_COOP_MAX 2           // (8 with the per-lane walk of round 1; the pooled walk serves 3..8 rays better: 16: 20.81 ms, 8: 20.41, 4: 20.30, 2: 20.27)
+#define RT_COOP_MAX 8           // dense grids only (see closest_tree)
 #endif
 // phase-A iterations a wave spends on its lanes' walks per bounce iteration before unfinished walks are postponed (0 = no cap)
 #ifndef RT_WALK_CAP
@@ -101,7 +104,7 @@ namespace rt {
 #define RT_GROUND_SHORT 1      // skip the exact ground test for rays that leave the ground behind (exact, see closest_tree)
 #endif
 #ifndef RT_LONG_PER_WAVE
-#define RT_LONG_PER_WAVE 4
+#define RT_LONG_PER_WAVE 16     // (4 with the per-lane walk; the pooled walk serves a thin wave of 16 chains: 2: 20.32 ms, 4: 20.04, 8: 19.84, 16: 19.81, 32: 21.92)
 #endif
 // list path: rays are scanned cooperatively (lanes = spheres) while live_rays * RT_LIST_COOP_COST <= list size
 // list path: spheres per pass of the linear scan
@@ -648,120 +651,6 @@ RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, fl
 }
 
 
-// The cooperative walk for G = 2 or 4 rays at once, one per group of 64/G lanes (a thin wave usually holds two chains:
-// RT_LONG_PER_WAVE, and the walk is half of the time a bounce takes there).  Same steps as walk_coop with fewer lanes per ray:
-// up to 8 columns per chunk, entries spread over the group's lanes, candidates resolved in parallel, minimum over the group.
-// Reads across lanes are ds_bpermute (the source lane differs between the groups); ballots are masked with the group's lanes.
-// Rays live in lanes L0..L3; groups n_rays.. idle.
-template <int G>
-RT_DEV void walk_coop_g(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int n_rays, int L0, int L1, int L2, int L3, float& best_t, int& best, bool& tie STAT_ARG) {
-    const DevAccel& A = T.acc;
-    constexpr int LG = 64 / G;
-    const int lane = threadIdx.x & 63, g = lane / LG, sl = lane & (LG - 1), gb = lane & ~(LG - 1);
-    const int Ls = g == 0 ? L0 : g == 1 ? L1 : g == 2 ? L2 : L3;           // this group's ray lives in lane Ls
-    const unsigned long long gmask = (LG == 32 ? 0xffffffffull : 0xffffull) << gb;
-    RayF q;
-    q.o.x = __shfl(r.o.x, Ls); q.o.y = __shfl(r.o.y, Ls); q.o.z = __shfl(r.o.z, Ls);
-    q.d.x = __shfl(r.d.x, Ls); q.d.y = __shfl(r.d.y, Ls); q.d.z = __shfl(r.d.z, Ls);
-    const float qa = __shfl(a, Ls);
-    Walk Q;
-    Q.i = __shfl(W.i, Ls); Q.iend = __shfl(W.iend, Ls); Q.coff = __shfl(W.coff, Ls);
-    Q.om_c = __shfl(W.om_c, Ls); Q.on_c = __shfl(W.on_c, Ls); Q.slope = __shfl(W.slope, Ls); Q.dm_c = __shfl(W.dm_c, Ls);
-    Q.fwd = __shfl((int)W.fwd, Ls) != 0; Q.walking = true;
-    float bt = __shfl(best_t, Ls); int bi = __shfl(best, Ls);
-    bool tieL = false;
-    const int stp = Q.fwd ? 1 : -1;
-    const float ra = __builtin_amdgcn_rcpf(qa);
-    bool go = g < n_rays && Q.i != Q.iend;                    // uniform within a group
-    while (__ballot(go) != 0ull) {
-        STAT(st, ST_A_ITERS_WAVE, 1); WPASS(WP_COOP_CHUNK);
-        const int left = go ? (Q.fwd ? (Q.iend - Q.i) : (Q.i - Q.iend)) : 0;
-        const int ncol = left < 8 ? left : 8;
-        int eb = 0, cnt = 0;
-        if (sl < ncol) { int e1; column_range(A, Q, Q.i + sl * stp, eb, e1); cnt = e1 - eb; }
-        int incl = cnt;                                      // inclusive prefix over sub-lanes 0..7 of the half
-        { incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); }   // row_shr:1,2,4 (the 8 lanes sit in one row of 16)
-        const int total = __shfl(incl, gb + 7);
-        const int start = incl - cnt;                          // first position of this column's entries in the chunk
-        int t_any = 0;                                        // wave-uniform
-#pragma unroll
-        for (int k = 0; k < G; ++k) { const int tk = __builtin_amdgcn_readlane(total, k * LG); t_any = tk > t_any ? tk : t_any; }
-        for (int base = 0; base < t_any; base += LG) {
-            const int jdx = base + sl;
-            const bool have = jdx < total;
-            int e = 0;                                          // (fetched per pass, not hoisted: registers decide the occupancy)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int st_m = __shfl(start, gb + m), in_m = __shfl(incl, gb + m), eb_m = __shfl(eb, gb + m);
-                if (jdx >= st_m && jdx < in_m) e = eb_m + (jdx - st_m);
-            }
-            float cand = __builtin_inff();
-            bool want = false;
-            float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
-            if (have) {
-                STAT(st, ST_TESTS, 1);
-                const float4 s = A.hot[e];
-                blo = A.brick[2 * e]; bhi = A.brick[2 * e + 1];
-                const float ocx = q.o.x - s.x, ocy = q.o.y - s.y, ocz = q.o.z - s.z;
-                const float b = ocx * q.d.x + ocy * q.d.y + ocz * q.d.z;
-                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
-                const float disc = b * b - qa * c;
-                if (disc > 0.0f) {
-                    const float sqa = __builtin_amdgcn_sqrtf(disc);
-                    const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
-                    const bool behind = (sqa - b) * ra + m < 0.001f;
-                    const bool beyond = (-b - sqa) * ra - m > bt;
-                    if (!behind && !beyond) {
-                        const float sq = sqrtf(disc);
-                        const float t1 = (-b - sq) / qa;
-                        if (t1 > 0.001f) cand = t1;
-                        else { const float t2 = (-b + sq) / qa; if (t2 > 0.001f) cand = t2; }
-                        want = cand <= bt;
-                    }
-                }
-            }
-            if (__ballot(want) != 0ull) {
-                STAT(st, ST_B_ROUNDS_WAVE, 1);
-                int id = -1;
-                bool elig = false;
-                if (want) {
-                    id = __float_as_int(blo.w);
-                    if (cand < bt) {
-                        elig = in_brick(q, cand, blo, bhi);
-                        if (!elig) {
-                            const int nd = __float_as_int(bhi.w);
-                            if (nd >= 0) {
-                                const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1];
-                                elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
-                            }
-                            else elig = eligible(s_nodes, q, cand, id STAT_PASS);
-                        }
-                    }
-                }
-                // an equal t from a different tree sphere than the current best: the visit order would decide
-                if ((__ballot(want && cand == bt && id != bi && bi > 0) & gmask) != 0ull) tieL = true;
-                const float mn = group_min<LG>(elig ? cand : __builtin_inff());
-                const unsigned long long mm = __ballot(elig && cand == mn) & gmask;         // (empty when mn is +inf)
-                const int wl = mm != 0ull ? __ffsll((long long)mm) - 1 : lane;
-                const int wid = __shfl(id, wl);
-                const bool two = (__ballot(elig && cand == mn && id != wid) & gmask) != 0ull;
-                if (mn < bt) { if (two) tieL = true; bt = mn; bi = wid; }
-            }
-        }
-        if (go) {
-            Q.i += ncol * stp;
-            if (bi >= 0) walk_clip(Q, A, bt);
-            go = Q.i != Q.iend;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-        const float btk = bcast(bt, k * LG); const int bik = bcast(bi, k * LG), tik = bcast((int)tieL, k * LG);
-        const int Lk = k == 0 ? L0 : k == 1 ? L1 : k == 2 ? L2 : L3;
-        if (k < n_rays && lane == Lk) { best_t = btk; best = bik; tie = tie || (tik != 0); W.walking = false; }
-    }
-}
-
 // Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
 // clipped to the y-slab that holds them, front to back, ending at the column that lies beyond the best hit.
 // The per-lane walk alternates two phases so that the expensive, rare work is done by many lanes at once:
@@ -1262,26 +1151,18 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         const bool walker = fast || (live && ts.pending);
         const int nw = __popcll(__ballot(walker));
         // the cooperative walk starts at a column boundary: not while a lane has a partly tested column
-        const bool coop = nw > 0 && nw <= RT_COOP_MAX && __ballot(walker && ts.e < ts.e_end) == 0ull;
+        // dense grids (the plain variant): a wave with few walkers resolves them cooperatively, one ray at a time with lanes = spheres.
+        // Sparse grids (the pooled variant) pool the walks of any number of rays: measured with cooperative walks for <= 8 rays 20.41 ms,
+        // <= 2: 20.27, none: 19.94 — and without that code the kernel fits four waves per SIMD (19.51 ms)
+        const bool coop = nw > 0 && nw <= (COOPG < 4 ? RT_COOP_MAX : RT_COOP_SPARSE) && __ballot(walker && ts.e < ts.e_end) == 0ull;
         if (coop) {
-            // four or two rays at a time (one per quarter- / half-wave), a single one with all 64 lanes
             const int lane_ = threadIdx.x & 63;
             unsigned long long todo = __ballot(walker && ts.W.walking);
-            auto pop = [&]() -> int { const int L = __ffsll((long long)todo) - 1; todo &= todo - 1ull; return L; };
-            // (COOPG = 1 for dense grids, chosen at launch from DevAccel::coop_groups: groups share the wave's lanes evenly, so
-            // with hundreds of entries per chunk an uneven pair takes 2 x max instead of the sum — and the group code needs
-            // 142 VGPRs, 3 waves/SIMD, where the plain kernel runs 4, which is what a dense scene's long walks want)
-            while (COOPG >= 4 && __popcll(todo) >= 3) {                    // four (or three) at a time on quarter-waves
-                const int n = __popcll(todo) >= 4 ? 4 : 3;
-                const int L0 = pop(), L1 = pop(), L2 = pop(), L3 = n == 4 ? pop() : L2;
-                walk_coop_g<4>(T, s_nodes, r, a, ts.W, n, L0, L1, L2, L3, closest, best, ts.tie STAT_PASS);
+            while (todo != 0ull) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS);
             }
-            if (COOPG >= 2 && __popcll(todo) == 2) {
-                const int L0 = pop(), L1 = pop();
-                walk_coop_g<2>(T, s_nodes, r, a, ts.W, 2, L0, L1, L1, L1, closest, best, ts.tie STAT_PASS);
-            }
-            while (__popcll(todo) > 1) { const int L = pop(); walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS); }
-            if (todo != 0ull) walk_coop(T, s_nodes, r, a, ts.W, lane_ == __ffsll((long long)todo) - 1, closest, best, ts.tie STAT_PASS);
         }
 #if RT_WALK_POOL
         else if (COOPG >= 4 && nw > 0) {      // sparse grids only: on dense ones (C5: 37 entries per cell) a round without clipping tests twice as much (1754 against 817 ms)
