@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
 #endif
 
 // hitTree / hitable_list::hit for a batch of rays (one lane per ray)
-template <bool TREE>
+template <bool TREE, int COOPG = 1>
 __global__ __launch_bounds__(256) void k_trace(RenderArgs A, const float* rays, long long n, rt_hit_record* out) {
     const DevScene& S = A.scene; const DevTree& T = A.tree;
     extern __shared__ float4 s_nodes[];
@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(256) void k_trace(RenderArgs A, const float* rays, 
         TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
         ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
         bool act = live;
-        do { closest_tree<1>(S, T, s_nodes, r, a, act, closest, best, ts STAT_PASS); act = live && ts.pending; } while (__ballot(act) != 0ull);
+        do { closest_tree<COOPG>(S, T, s_nodes, r, a, act, closest, best, ts STAT_PASS); act = live && ts.pending; } while (__ballot(act) != 0ull);
     } else closest_list(S, r, a, live, closest, best);
     if (!live) return;
     rt_hit_record h;
@@ -1874,7 +1874,9 @@ hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const fl
     RenderArgs A{};
     A.scene = S; A.tree = T;
     if (!tree) return launch_trace_list(A, blocks, rays, n, out, st);
-    hipLaunchKernelGGL((k_trace<true>), dim3(blocks), dim3(256), tree_lds_bytes(T.n_nodes), st, A, rays, n, out);
+    // the walk the render kernel would use for this tree (sparse grids: the pooled walk), so that per-ray parity checks cover it
+    if (render_variant(true, 0, T.acc) == 4) hipLaunchKernelGGL((k_trace<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(T.n_nodes, true), st, A, rays, n, out);
+    else hipLaunchKernelGGL((k_trace<true>), dim3(blocks), dim3(256), tree_lds_bytes(T.n_nodes), st, A, rays, n, out);
     return hipGetLastError();
 }
 
