@@ -10,8 +10,9 @@
 //     queue (one pixel position of 64 different tiles per wave: long chains cluster), most expensive tiles first;
 //   * the reference's `for sample { for bounce {..} }` nest is flattened into ONE loop per lane: a lane whose path
 //     ended starts its next sample at once instead of idling until the slowest path of the wave finishes;
-//   * octree on: candidates come from an exact culling grid (rt_accel.h), the reference's traversal is the fallback;
-//     waves holding long pixel chains stop refilling ("thin") and resolve their few rays cooperatively, lanes = spheres;
+//   * octree on: candidates come from an exact culling grid (rt_accel.h), the reference's traversal is the fallback; on sparse
+//     grids the wave's sphere tests are pooled and dealt out evenly over its 64 lanes (walk_pool), on dense ones every lane
+//     walks its own columns (walk_lanes); waves holding long pixel chains stop refilling ("thin");
 //   * no virtual calls, no device heap, no recursion: materials are a tag + 4 floats, the octree is a pre-order
 //     node array with skip links staged in LDS, bucket contents are pre-gathered (centre, r^2) float4 streams;
 //   * hitable_list path: the sphere index is wave-uniform, so sphere data comes through scalar loads (SGPR operands).
@@ -37,19 +38,13 @@ namespace rt {
 #ifndef RT_RENDER_WAVES
 #define RT_RENDER_WAVES 4
 #endif
-// grid entries tested per walk step (loads in flight together): on sparse grids (C3: 3.6 entries per cell; the kernel variant
-// with grouped cooperative walks) / on dense grids (C5: 37 per cell; the plain variant).  Measured: C3 4: 22.9 ms, 6: 22.7, 8: 23.5;
-// C5 4: 144.8 ms, 6: 133.5, 8: 129.6.
-#ifndef RT_BATCH_SPARSE
-#define RT_BATCH_SPARSE 6
-#endif
+// The per-lane walk (walk_lanes) serves dense grids (C5: 37 entries per cell; the plain kernel variant); sparse grids (C3: 3.6 per
+// cell) take the pooled walk (walk_pool, the variant k_render<true,0,4>).
+// grid entries tested per step of the per-lane walk (loads in flight together).  C5 4: 144.8 ms, 6: 133.5, 8: 129.6
 #ifndef RT_BATCH_DENSE
 #define RT_BATCH_DENSE 8
 #endif
-// phase B starts when holders * VOTE >= searchers (or nobody searches); sparse / dense grids (C5: 2 -> 126 ms, 3 -> 122, 5 -> 120)
-#ifndef RT_VOTE_SPARSE
-#define RT_VOTE_SPARSE 3
-#endif
+// phase B of the per-lane walk starts when holders * VOTE >= searchers (or nobody searches) (C5: 2 -> 126 ms, 3 -> 122, 5 -> 120)
 #ifndef RT_VOTE_DENSE
 #define RT_VOTE_DENSE 5
 #endif
@@ -819,9 +814,6 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
 // min.  An atomic min that meets an equal t from another sphere flags the exact tie (-> reference scan), as `offer` does.
 // Nothing here decides a hit differently: the same candidates' exact values, merged by a minimum instead of one after the other;
 // testing MORE spheres than walk_lanes would (no clipping inside a round) cannot change the minimum (App. A.4).
-#ifndef RT_WALK_POOL
-#define RT_WALK_POOL 1
-#endif
 #ifndef RT_POOL_COLS
 #define RT_POOL_COLS 2
 #endif
@@ -1164,7 +1156,6 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS);
             }
         }
-#if RT_WALK_POOL
         else if (COOPG >= 4 && nw > 0) {      // sparse grids only: on dense ones (C5: 37 entries per cell, ~100 per column) a round does not clip and filters against a stale best hit: 1754 ms with two columns per round, 1281 with one, against 817 for the per-lane walk
             // every lane of the wave takes part: lanes without a walk of their own test other lanes' spheres
             WalkLds& L = *((WalkLds*)(s_nodes + T.n_nodes * 3) + (threadIdx.x >> 6));
@@ -1174,9 +1165,6 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             if (walker) { ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
         }
         else if (walker) walk_lanes<RT_BATCH_DENSE, RT_QUORUM_DENSE, RT_VOTE_DENSE>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
-#else
-        else if (walker) walk_lanes<(COOPG >= 4 ? RT_BATCH_SPARSE : RT_BATCH_DENSE), (COOPG >= 4 ? RT_QUORUM_SPARSE : RT_QUORUM_DENSE), (COOPG >= 4 ? RT_VOTE_SPARSE : RT_VOTE_DENSE)>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
-#endif
         if (walker) {
             ts.pending = ts.W.walking;
             if (!ts.pending && ts.tie) { closest = ts.g_t; best = ts.g_id; slow = true; STAT(st, ST_TIE, 1); }
@@ -1783,7 +1771,7 @@ hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part,
 #endif
 
 // LDS of a block of the tree kernels: the nodes, then one WalkLds per wave
-static size_t tree_lds_bytes(int n_nodes, bool pool = false) { return (size_t)n_nodes * sizeof(DevNode) + (RT_WALK_POOL && pool ? 4 * sizeof(WalkLds) : 0); }
+static size_t tree_lds_bytes(int n_nodes, bool pool = false) { return (size_t)n_nodes * sizeof(DevNode) + (pool ? 4 * sizeof(WalkLds) : 0); }
 
 // blocks the chip holds at once for one render kernel variant (occupancy query, cached); the persistent grid is never
 // larger than that, and never larger than the work
