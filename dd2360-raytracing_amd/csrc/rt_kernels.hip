@@ -973,7 +973,11 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
                 const unsigned begin = min((unsigned)(lane + 64 * j) * C, total);
                 S.end = min(begin + C, total); S.cur = begin; S.seg_end = begin; S.base = 0u; S.sg = 0u; S.owner = -1;
                 S.q.o = {0.f, 0.f, 0.f}; S.q.d = {0.f, 1.f, 0.f}; S.a = 1.0f; S.abt = 0.0f; S.atm = 0.0f;
-                if (begin < S.end) {
+                if (n_seg <= 4u) {
+                    // a thin wave's round: a handful of ranges — three independent LDS reads instead of a chain of eight
+                    const unsigned p1 = L.pref[min(1u, n_seg - 1u)], p2 = L.pref[min(2u, n_seg - 1u)], p3 = L.pref[min(3u, n_seg - 1u)];
+                    S.sg = (n_seg > 1u && p1 <= begin ? 1u : 0u) + (n_seg > 2u && p2 <= begin ? 1u : 0u) + (n_seg > 3u && p3 <= begin ? 1u : 0u);
+                } else if (begin < S.end) {
                     unsigned lo = 0u, hi = n_seg;
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {                 // kWalkPool <= 256
