@@ -31,6 +31,7 @@ hipError_t read_h16_stats(unsigned long long* out, int reset);
 #ifdef RT_STATS
 hipError_t read_stats(unsigned long long* out, int reset);
 hipError_t read_wave_dbg(unsigned long long* out);
+hipError_t read_pilot_dbg(int* out, int n);
 #endif
 }
 
@@ -231,7 +232,7 @@ static int ctx_reserve(rt_render_ctx& C, int64_t tiles) {
     int rc = free_all(old, 4);
     if (rc) return rc;
     void* nw[4] = {nullptr, nullptr, nullptr, nullptr};
-    const size_t bytes[4] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 64, sizeof(unsigned int) * (size_t)tiles * 64};
+    const size_t bytes[4] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 80, sizeof(unsigned int) * (size_t)tiles * 64};
     for (int k = 0; k < 4; ++k) {
         const hipError_t e = hipMalloc(&nw[k], bytes[k]);
         if (e != hipSuccess) { (void)free_all(nw, 4); return (int)e; }
@@ -791,6 +792,7 @@ int rt_debug_h16(unsigned long long* out8, int reset) { return (int)rt::read_h16
 // diagnostic build only (librt_amd_stats.so): 16 work counters, see rt_kernels.hip
 int rt_debug_stats(unsigned long long* out16, int reset) { return (int)read_stats(out16, reset); }
 int rt_debug_waves(unsigned long long* out) { return (int)read_wave_dbg(out); }
+int rt_debug_pilot(int* out, int n) { return (int)read_pilot_dbg(out, n); }
 #endif
 
 // ------------------------------------------------------------------------------------------------ output

@@ -84,12 +84,15 @@ namespace rt {
 #define RT_QUORUM_MIN 16
 #endif
 
-// pilot classification: a pixel whose RT_PILOT_SAMPLES pilot samples total at least RT_PILOT_LONG bounces is started as a long chain
+// pilot classification: the pixels of a 2x2 block are started as long chains when the pilot bounces of the block and its eight
+// neighbours (RT_PILOT_SAMPLES samples each) total at least RT_PILOT_LONG_SUM.  Measured on C3 against the chains' true lengths
+// (tools/predictor.py): a block's own pilot >= 50 finds 22 % of the pixels above 1280 iterations and 62 % of those above 2000;
+// the 3x3 sum >= 200 finds 86 % and 100 %, and 1 % of what it selects is shorter than 400 iterations.
 #ifndef RT_PILOT_SAMPLES
 #define RT_PILOT_SAMPLES 2
 #endif
-#ifndef RT_PILOT_LONG
-#define RT_PILOT_LONG 50
+#ifndef RT_PILOT_LONG_SUM
+#define RT_PILOT_LONG_SUM 200
 #endif
 #ifndef RT_PILOT_CAP
 #define RT_PILOT_CAP 35     // bounces after which a pilot sample is cut (the pilot pass is as long as its longest chain; 50 = the reference's depth limit)
@@ -97,6 +100,9 @@ namespace rt {
 // long chains started per thin wave
 #ifndef RT_GROUND_SHORT
 #define RT_GROUND_SHORT 1      // skip the exact ground test for rays that leave the ground behind (exact, see closest_tree)
+#endif
+#ifndef RT_LONG_STRIDE
+#define RT_LONG_STRIDE 1
 #endif
 #ifndef RT_LONG_PER_WAVE
 #define RT_LONG_PER_WAVE 16     // (4 with the per-lane walk; the pooled walk serves a thin wave of 16 chains: 2: 20.32 ms, 4: 20.04, 8: 19.84, 16: 19.81, 32: 21.92)
@@ -126,6 +132,7 @@ enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFE
        TH_GROUND, TH_LARGE_SETUP, TH_WALK, TH_SCAN, ST_N };
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_stats[ST_N];
+__device__ int g_pilot_dbg[1 << 20];                  // per 2x2 block (tile * 16 + block): the pilot's bounce count
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
 struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
 #define STAT(st, k, v) ((st).c[k] += (v))
@@ -1418,7 +1425,15 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         const RenderArgs& A = *cold_args();
         const unsigned int h = atomicAdd(A.queue + 3, 1u);
         if (h >= n_long) { long_done = true; return false; }
+        // the list is in the pilot's order, the four pixels of a 2x2 block and the blocks of a tile next to each other — and
+        // neighbours are chains of like length: a stride (a prime that does not divide the count, so a permutation) puts
+        // them into different waves, where each is left alone with its wave once the shorter ones have ended
+#if RT_LONG_STRIDE
+        const unsigned int stride = n_long % 257u ? 257u : (n_long % 263u ? 263u : 269u);
+        const long long pid = (long long)A.long_list[(unsigned int)(((unsigned long long)h * stride) % n_long)];
+#else
         const long long pid = (long long)A.long_list[h];
+#endif
         const long long local_tile = pid >> 6;
         const int l = (int)(pid & 63);
         const long long tile = A.part + local_tile * A.nparts;
@@ -1588,10 +1603,10 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 // (ns samples x bounces on one RNG stream); with only a few pixels per resident lane, a long chain picked up late keeps
 // a nearly empty wave running.  k_tile_cost traces one PILOT sample per pixel on a private RNG stream and counts its
 // bounces: the tile sums feed k_tile_order (8 cost classes, most expensive first, stable), and pixels whose pilot path
-// reaches RT_PILOT_LONG bounces are listed as long chains, which the render kernel starts first, in thin waves.
+// neighbourhood reaches RT_PILOT_LONG_SUM bounces (k_long_select) are listed as long chains, which the render kernel starts first, in thin waves.
 // All of this changes only WHICH lane renders a pixel and WHEN, never the pixel.
 template <bool TREE, int COOPG = 1>
-__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ long_flag, unsigned int* __restrict__ long_list) {
+__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ pilot) {
     extern __shared__ float4 s_nodes[];
     if (TREE) {
         const int n4 = A.tree.n_nodes * 3;
@@ -1641,17 +1656,10 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     }
     int pix = inside ? bounces : 0;
     for (int off = RT_PILOT_SAMPLES / 2; off > 0; off >>= 1) pix += __shfl_xor(pix, off);       // sum over the pixel's samples
-    const bool is_long = inside && pix >= RT_PILOT_LONG;
-    if (long_flag && tile_ok && smp == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                          // the 2x2 block this pilot pixel stands for
-            const int px = lx + (q & 1), py = ly + (q >> 1);
-            const bool in_img = (tx * 8 + px < A.max_x) && (ty * 8 + py < A.max_y);
-            const long long pid = local_tile * 64 + py * 8 + px;
-            long_flag[pid] = (is_long && in_img) ? 1 : 0;
-            if (is_long && in_img) { const unsigned int pos = atomicAdd(A.queue + 2, 1u); long_list[pos] = (unsigned int)pid; }
-        }
-    }
+#ifdef RT_STATS
+    if (tile_ok && smp == 0 && local_tile * 16 + sub < (1 << 20)) g_pilot_dbg[local_tile * 16 + sub] = inside ? pix : -1;
+#endif
+    if (pilot && tile_ok && smp == 0) pilot[local_tile * 16 + sub] = (unsigned char)(pix < 255 ? pix : 255);       // per 2x2 block, for k_long_select
     int w = inside ? bounces : 0;
     for (int off = kPerTile / 2; off > 0; off >>= 1) w += __shfl_xor(w, off);         // sum over the tile's 16 pilot pixels x samples
     if (lane % kPerTile == 0 && tile_ok) cost[local_tile] = w * 4;
@@ -1659,8 +1667,45 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
 
 RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (c > 7 ? 7 : c); }
 
-// one block of 16 waves: stable counting sort of the tiles by cost class, descending (each wave takes a contiguous chunk)
 #ifndef RT_TU_LIST
+// one thread per 2x2 block: the pilot counts of the block and its eight neighbours decide whether its pixels start as long chains.
+// A neighbour outside the frame, or in a tile of another part of a partitioned frame, counts as the block itself.
+__global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigned char* __restrict__ pilot, unsigned char* __restrict__ long_flag,
+                                                    unsigned int* __restrict__ long_list) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= A.n_local_tiles * 16) return;
+    const long long local_tile = g >> 4;
+    const int sub = (int)(g & 15);
+    const long long tile = A.part + local_tile * A.nparts;
+    const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+    const int bx = tx * 4 + (sub & 3), by = ty * 4 + (sub >> 2);
+    const int own = pilot[g];
+    int sum = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int nx_ = bx + dx, ny_ = by + dy;
+            int v = own;
+            if (nx_ >= 0 && ny_ >= 0 && nx_ < A.tiles_x * 4 && ny_ < A.tiles_y * 4) {
+                const long long nt = (long long)(ny_ >> 2) * A.tiles_x + (nx_ >> 2) - A.part;
+                if (nt >= 0 && nt % A.nparts == 0) v = pilot[(nt / A.nparts) * 16 + (ny_ & 3) * 4 + (nx_ & 3)];
+            }
+            sum += v;
+        }
+    const bool is_long = sum >= RT_PILOT_LONG_SUM;
+    const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                          // the 2x2 block this pilot pixel stands for
+        const int px = lx + (q & 1), py = ly + (q >> 1);
+        const bool in_img = (tx * 8 + px < A.max_x) && (ty * 8 + py < A.max_y);
+        const long long pid = local_tile * 64 + py * 8 + px;
+        long_flag[pid] = (is_long && in_img) ? 1 : 0;
+        if (is_long && in_img) { const unsigned int pos = atomicAdd(A.queue + 2, 1u); long_list[pos] = (unsigned int)pid; }
+    }
+}
+
+// one block of 16 waves: stable counting sort of the tiles by cost class, descending (each wave takes a contiguous chunk)
 __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n) {
     __shared__ int s_cnt[16][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1796,8 +1841,8 @@ template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
 #else
 #define RT_LIST_FN(name) static name##_list
 #endif
-hipError_t RT_LIST_FN(launch_tile_cost)(const RenderArgs& A, unsigned blocks, int* cost, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
-    hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), 0, st, A, cost, flags, long_list);
+hipError_t RT_LIST_FN(launch_tile_cost)(const RenderArgs& A, unsigned blocks, int* cost, unsigned char* pilot, hipStream_t st) {
+    hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), 0, st, A, cost, pilot);
     return hipGetLastError();
 }
 hipError_t RT_LIST_FN(launch_render)(const RenderArgs& A, int mode, hipStream_t st) {
@@ -1813,7 +1858,7 @@ hipError_t RT_LIST_FN(launch_trace)(const RenderArgs& A, unsigned blocks, const 
     return hipGetLastError();
 }
 #else
-hipError_t launch_tile_cost_list(const RenderArgs& A, unsigned blocks, int* cost, unsigned char* flags, unsigned int* long_list, hipStream_t st);
+hipError_t launch_tile_cost_list(const RenderArgs& A, unsigned blocks, int* cost, unsigned char* pilot, hipStream_t st);
 hipError_t launch_render_list(const RenderArgs& A, int mode, hipStream_t st);
 hipError_t launch_trace_list(const RenderArgs& A, unsigned blocks, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 #endif
@@ -1839,9 +1884,12 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     const long long per_block = 4 * (64 / (16 * RT_PILOT_SAMPLES));       // a wave covers 4 / RT_PILOT_SAMPLES tiles
     const unsigned blocks = (unsigned)((A.n_local_tiles + per_block - 1) / per_block);
     // (sparse grids: the pilot paths walk the grid like the render kernel's full waves do, through the wave's pool)
-    if (tree && render_variant(true, 0, A.tree.acc) == 4 && RT_PILOT_POOL) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, flags, long_list);
-    else if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, flags, long_list);
-    else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, flags, long_list, st); if (e != hipSuccess) return e; }
+    // flags: 64 bytes per local tile (one per pixel) followed by 16 per local tile (the pilot counts per 2x2 block)
+    unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
+    if (tree && render_variant(true, 0, A.tree.acc) == 4 && RT_PILOT_POOL) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
+    else if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
+    else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
+    if (flags) hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, (const unsigned char*)pilot, flags, long_list);
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
     return hipGetLastError();
 }
@@ -1883,6 +1931,7 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
 #endif
 
 #ifdef RT_STATS
+hipError_t read_pilot_dbg(int* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pilot_dbg), sizeof(int) * (size_t)(n < (1 << 20) ? n : (1 << 20))); }
 hipError_t read_wave_dbg(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_dbg), sizeof(unsigned long long) * 8192 * 4); }
 hipError_t read_stats(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * ST_N);

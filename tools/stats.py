@@ -52,6 +52,13 @@ for lo, hi in ((0, 200), (200, 400), (400, 800), (800, 1280), (1280, 4000)):
     if m.any():
         print("  pixels with %4d-%4d iterations: %7d, start p50 %.1f p90 %.1f max %.1f ms; end p50 %.1f p99 %.1f max %.1f ms; us/iteration p50 %.1f" % (
             lo, hi, m.sum(), *np.percentile(tstart[m], [50, 90, 100]), *np.percentile(tend[m], [50, 99, 100]), np.percentile(((tend - tstart)[m] / np.maximum(it[m], 1)) * 1e3, 50)))
+if os.environ.get("RT_STATS_DUMP"):           # per-pixel iterations + the pilot's per-block counts, for tools/predictor.py
+    nt = ((nx + 7) // 8) * ((ny + 7) // 8)
+    pb = (C.c_int * (nt * 16))()
+    L.rt_debug_pilot.restype = C.c_int; L.rt_debug_pilot.argtypes = [C.c_void_p, C.c_int]
+    L.rt_debug_pilot(pb, nt * 16)
+    np.savez_compressed(os.environ["RT_STATS_DUMP"], it=it.astype(np.uint16), pilot=np.array(pb, dtype=np.int16).reshape(nt, 16),
+                        tstart=tstart.astype(np.float32), tend=tend.astype(np.float32))
 rows = it.mean(axis=1)
 print("row means of iterations (every 50 rows from bottom):", " ".join("%.0f" % rows[k] for k in range(0, ny, 50)))
 worst = np.argsort(it.ravel())[-5:]
