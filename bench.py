@@ -280,6 +280,7 @@ def main():
         call_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))       # whole rt_render call (pre-pass + kernel)
         kt = W.render_times()                                        # HIP events around the render kernel itself, on its stream
         kernel_ms = sum(kt) / max(1, len(kt))
+    long_chains = None if world > 1 else W.render_counters()["long_chains"]      # pixels the pilot pass started as long chains (last frame)
     samples_step = nx * ny * spp                                  # whole job, all ranks
     local_samples = rt.part_pixels(nx, ny, rt.Partition(rank, world)) * spp if world > 1 else samples_step
     value = samples_step * args.steps / dt / 1e6
@@ -322,6 +323,7 @@ def main():
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
                          "frac_unfused": round(achieved / PEAK_UNFUSED_TOPS, 5), "peak_unfused": PEAK_UNFUSED_TOPS,
                          "kernel_ms": round(kernel_ms, 4), "render_call_ms": round(call_ms, 4), "flops_per_sample": cfg["flops_per_sample"],
+                         "long_chains_preclassified": long_chains,
                          "note": "ALGORITHMIC unfused flops of the reference's visit set (SURVEY 8d: every sphere of every visited bucket, "
                                  "or of the whole list) / device time of the render kernel (HIP events on its stream%s).  The fp32 kernels "
                                  "find the same hits with ~20x fewer sphere tests (exact culling grid), so this is delivered algorithmic "

@@ -690,6 +690,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     // counters ring's neighbours and the workspace (a no-op on the same stream)
     if (!cap && C.has_done && C.last_stream != st) RT_TRY(hipStreamWaitEvent(st, C.done, 0));
     A.queue = C.d_queue + (size_t)(C.launches++ % kQueueSlots) * kQueueStride;
+    C.last_queue = A.queue;
     RT_TRY(launch_zero_counters(A.queue, 4, st));
     if (sched) {
         const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long
@@ -724,6 +725,21 @@ static int ctx_times(rt_render_ctx& C, float* ms_out, int max, int* count) {
     *count = n;
     C.ev_count = 0;
     return 0;
+}
+// the scheduling counters of the context's latest launch, once it has finished
+static int ctx_counters(rt_render_ctx& C, uint32_t* out4) {
+    if (!C.last_queue) { out4[0] = out4[1] = out4[2] = out4[3] = 0u; return 0; }
+    if (C.has_done) RT_TRY(hipEventSynchronize(C.done));
+    RT_TRY(hipMemcpy(out4, C.last_queue, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+int rt_world_render_counters(rt_world* W, uint32_t* out4) {
+    if (!W || !out4) return RT_EINVAL;
+    return ctx_counters(W->z->ctx, out4);
+}
+int rt_render_ctx_counters(rt_render_ctx* C, uint32_t* out4) {
+    if (!C || !out4) return RT_EINVAL;
+    return ctx_counters(*C, out4);
 }
 int rt_world_render_times(rt_world* W, float* ms_out, int max, int* count) {
     if (!W || !ms_out || !count || max < 0) return RT_EINVAL;

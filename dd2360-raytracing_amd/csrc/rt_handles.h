@@ -23,6 +23,7 @@ struct rt_render_ctx {
     unsigned int* d_queue = nullptr; unsigned launches = 0;
     // scheduling workspace (tile costs, hand-out order, long-chain flags and list), grown on demand
     int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
+    unsigned int* last_queue = nullptr;      // the counters of the latest launch (rt_render_ctx_counters)
     // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_render_ctx_times
     hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
     // ordering of successive launches that share this context

@@ -75,6 +75,8 @@ SYMBOLS = {
     "rt_render_on": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
     "rt_render_progressive_on": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, Partition, _vp]),
     "rt_render_ctx_times": (_i, [_vp, _vp, _i, _vp]),
+    "rt_render_ctx_counters": (_i, [_vp, _vp]),
+    "rt_world_render_counters": (_i, [_vp, _vp]),
     "rt_render_kernel_name": (_i, [_vp, _vp, _i, _vp, _i]),
     "rt_multi_unique_id": (_i, [_vp]),
     "rt_multi_init": (_i, [_vp, _i, _i, _vp]),
@@ -169,6 +171,12 @@ class RenderCtx:
         n = C.c_int(0)
         check(lib().rt_render_ctx_times(self.h, _np(out), 64, C.byref(n)), "rt_render_ctx_times")
         return out[: n.value].tolist()
+
+    def counters(self):
+        """scheduling counters of the latest launch: slots handed out, thin waves left, long chains pre-classified, handles taken"""
+        out = np.zeros(4, np.uint32)
+        check(lib().rt_render_ctx_counters(self.h, _np(out)), "rt_render_ctx_counters")
+        return dict(zip(("slots", "thin_waves", "long_chains", "long_handles"), (int(v) for v in out)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -292,6 +300,12 @@ class World:
         n = C.c_int(0)
         check(lib().rt_world_render_times(self.h, _np(out), 64, C.byref(n)), "rt_world_render_times")
         return out[: n.value].tolist()
+
+    def render_counters(self):
+        """scheduling counters of the latest render() on this world (see RenderCtx.counters)"""
+        out = np.zeros(4, np.uint32)
+        check(lib().rt_world_render_counters(self.h, _np(out)), "rt_world_render_counters")
+        return dict(zip(("slots", "thin_waves", "long_chains", "long_handles"), (int(v) for v in out)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -207,6 +207,13 @@ int rt_render_kernel_name(const rt_world* world, const rt_octree* d_octree, int 
  * stores how many in *count, and forgets them.  Synchronises with the recorded events. */
 int rt_world_render_times(rt_world* world, float* ms_out, int max, int* count);
 
+/* Scheduling counters of the most recent rt_render on this world / context, read once that launch has finished (waits for it):
+ * out4[0] = pixel slots handed out by the work queue, [1] = waves still counted thin (0 after a complete frame), [2] = pixels the
+ * pilot pass pre-classified as long chains (0 below 16 samples per pixel or on the binary16 path), [3] = long-chain handles
+ * taken.  Diagnostics only — no counterpart in the reference; which lane renders a pixel never changes the pixel. */
+int rt_world_render_counters(rt_world* world, uint32_t* out4);
+int rt_render_ctx_counters(rt_render_ctx* ctx, uint32_t* out4);
+
 /* Reassemble a full row-major frame from nparts tile-major part buffers laid out back to back, each padded to
  * rt_part_pixels(max_x,max_y,{0,nparts}) elements (the layout an all-gather of the parts produces). */
 int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream);

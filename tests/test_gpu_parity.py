@@ -181,6 +181,41 @@ def test_partition_assemble_equals_whole(rt, cuda, nparts):
     assert torch.equal(full.view(torch.int32), whole.view(torch.int32))
 
 
+@pytest.mark.parametrize("nparts", [1, 3])
+def test_long_chain_selection_on_ragged_and_partitioned_frames(rt, cuda, nparts):
+    """From 16 samples per pixel on, the pilot pass and k_long_select pre-classify long chains from the pilot counts of a 2x2 block
+    and its eight neighbours.  A ragged frame (603 x 403: edge tiles with pixels outside), whole and as three parts whose tiles'
+    neighbours belong to the other parts: every pixel is rendered exactly once, bit-equal to the oracle (frame and RNG state),
+    and the scheduling counters show that chains were pre-classified and all handed out."""
+    torch = cuda
+    nx, ny, ns, n = 603, 403, 16, 500
+    W = rt.World(n, nx, ny)
+    O = rt.Octree(W, 30)
+    ref, ref_st = OracleScene(n, nx, ny, use_octree=True, spl=30).render(ns, nthreads=8)
+    per = rt.part_pixels(nx, ny, rt.Partition(0, nparts))
+    parts = torch.zeros(nparts * per * 3, dtype=torch.float32, device="cuda")
+    n_long = 0
+    for p in range(nparts):
+        part = rt.Partition(p, nparts)
+        fb, st = gpu_render(rt, torch, W, O, nx, ny, ns, part)
+        c = W.render_counters()
+        assert c["thin_waves"] == 0
+        assert c["long_handles"] >= c["long_chains"]              # every pre-classified chain was taken (handles past the end find the list empty)
+        n_long += c["long_chains"]
+        if nparts == 1:
+            got = fb.cpu().numpy().reshape(ny, nx, 3)
+            assert np.array_equal(bits(got), bits(ref))
+            assert np.array_equal(st.cpu().numpy().view(np.uint32).reshape(-1, 12)[:, :6], ref_st[:, :6])
+        else:
+            parts[p * per * 3: p * per * 3 + fb.numel()] = fb
+    if nparts > 1:
+        full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda")
+        rt.assemble(full, parts, nx, ny, nparts)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(full.cpu().numpy().reshape(ny, nx, 3)), bits(ref))
+    assert 0 < n_long <= nx * ny // 64, n_long
+
+
 def test_render_progressive(rt, cuda):
     """render_progressive: accumulation and RNG continuation equal the oracle's after 3 passes."""
     torch = cuda
