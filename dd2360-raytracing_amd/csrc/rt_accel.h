@@ -54,6 +54,10 @@ constexpr double kSlack = 2e-3;         // rasterisation slack (absorbs float er
 // rounded up.  (0.012 cost 2.7 % of the C3 frame: the lowest 3 % of a sphere resting on y = 0 fell outside its brick.)
 constexpr double kBrickMxz = 0.0008, kBrickMy = 0.0085;
 // 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
+#ifndef RT_DENSE_CELL
+#define RT_DENSE_CELL 0.7
+#endif
+constexpr double kDenseCell = RT_DENSE_CELL;     // cell size of dense scenes, in units of 2 R' (build_accel step 2, and the device build)
 __host__ __device__ inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
 // inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
 __host__ __device__ inline double accel_Rp(double r2) { return sqrt(r2 * (1.0 + 1e-6) + accel_K2()) + 1e-5 + kSlack; }
@@ -147,7 +151,7 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         // tests per ray go with the cell size, columns per ray against it (C5, 37 per cell: 129.5 -> 122.4 ms at 0.7, 125.4 at
         // 0.5; C3, 3.6 per cell: 22.7 -> 23.2 ms at 0.7, so sparse scenes keep 2R')
         const double g = std::ceil(2.0 * (11.0 + 5.0 * h) / h);
-        if (4.0 * (double)radii.size() > 8.0 * g * g) h = std::max(0.05, 0.7 * h);
+        if (4.0 * (double)radii.size() > 8.0 * g * g) h = std::max(0.05, kDenseCell * h);
     }
     const double Rlim = 1.5 * h;                               // spheres with R' above this go to the large list
     // extent: the reference's root box in x and z (every tree sphere's centre lies in it, grown by its radius); a list may

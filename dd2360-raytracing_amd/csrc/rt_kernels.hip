@@ -1079,6 +1079,161 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
     W.walking = walking;
 }
 
+// The pooled walk for DENSE grids (C5: ~30 entries per cell, 60-100 per column).  One column per walking lane and round; a lane
+// steps through its span RT_DENSE_PB entries at a time (their loads in flight together, like walk_lanes' batches) and filters
+// against the owner's CURRENT best hit, re-read from the wave's LDS every pass — on a dense grid most of a column lies behind the
+// first hit, and a filter that only knew the hit of the previous round would send all of it to the candidate queue.  The queue is
+// drained from RT_DENSE_DRAIN candidates on, so that a found hit starts rejecting soon.
+#ifndef RT_DENSE_POOL
+#define RT_DENSE_POOL 1
+#endif
+#ifndef RT_DENSE_PB
+#define RT_DENSE_PB 4
+#endif
+#ifndef RT_DENSE_DRAIN
+#define RT_DENSE_DRAIN 32
+#endif
+template <int RT_QUORUM_DEN>
+RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L, const RayF& r, float a, Walk& W, float& best_t, int& best, bool& tie STAT_ARG) {
+    constexpr int PB = RT_DENSE_PB;
+    const DevAccel& A = T.acc;
+    const int32_t* __restrict__ cs = A.cs;
+    const float4* __restrict__ hot = A.hot;
+    const int lane = threadIdx.x & 63;
+    const int G = A.G;
+    const float fG = (float)G, fGm = fG - 0.5f, s_c = 2e-3f * A.inv_h;
+    const int step = W.fwd ? 1 : -1;
+    bool walking = W.walking && W.i != W.iend;
+    const int nw0 = __popcll(__ballot(walking));
+    L.ray[2 * lane] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+    while (true) {
+        L.ray[2 * lane + 1] = make_float4(r.d.y, r.d.z, a, __builtin_fmaf(a * best_t, 1.0001f, 1e-6f * a));
+        L.key[lane] = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)best;
+        if (lane == 0) { L.tie_lo = 0u; L.tie_hi = 0u; }
+        walk_sync();
+        // ---- phase 1: the entry range of the next column of every walking lane
+        int e0 = 0, e1 = 0;
+        if (walking && W.i != W.iend) {
+            STAT(st, ST_COLS, 1);
+            const float u0 = W.on_c + ((float)W.i - W.om_c) * W.slope, u1 = u0 + W.slope;
+            const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
+            if (hi >= 0.0f && lo < fG) {
+                const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGm);
+                const unsigned cbase = (unsigned)(W.coff + W.i * G);
+                e0 = cs[cbase + (unsigned)k0]; e1 = cs[cbase + (unsigned)k1 + 1u];
+            }
+            W.i += step;
+        }
+        const bool has = e1 > e0;
+        const unsigned long long m = __ballot(has);
+        const unsigned n_seg = (unsigned)__popcll(m);
+        if (has) {
+            const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            L.seg[slot] = make_uint2((unsigned)e0, (unsigned)(e1 - e0) | ((unsigned)lane << 26));
+        }
+        walk_sync();
+        if (n_seg != 0u) {
+            // ---- phase 2: prefix of the ranges, an equal span of the concatenated entries per lane
+            unsigned total;
+            {
+                const unsigned cnt = (unsigned)lane < n_seg ? (L.seg[lane].y & 0x3ffffffu) : 0u;
+                const unsigned ex = walk_excl_scan(cnt, total);
+                if ((unsigned)lane < n_seg) L.pref[lane] = ex;
+            }
+            walk_sync();
+            const unsigned C = (total + 63u) / 64u;
+            PoolSpan S;
+            const unsigned begin = min((unsigned)lane * C, total);
+            S.end = min(begin + C, total); S.cur = begin; S.seg_end = begin; S.base = 0u; S.sg = 0u; S.owner = lane;
+            S.q.o = {0.f, 0.f, 0.f}; S.q.d = {0.f, 1.f, 0.f}; S.a = 1.0f; S.abt = 0.0f; S.atm = 0.0f;
+            if (begin < S.end) {
+                unsigned lo = 0u, hi = n_seg;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {                     // n_seg <= 64
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; }
+                }
+                S.sg = lo;
+            }
+            // ---- phase 3: the tests
+            unsigned qn = 0u;
+            while (true) {
+                const bool act = S.cur < S.end;
+                if (__ballot(act) == 0ull) break;
+                STAT(st, ST_A_ITERS_WAVE, 1);
+                if (act && S.cur >= S.seg_end) {
+                    const uint2 sd = L.seg[S.sg];
+                    const unsigned p0 = L.pref[S.sg];
+                    ++S.sg;
+                    S.seg_end = p0 + (sd.y & 0x3ffffffu);
+                    S.base = sd.x - p0;
+                    S.owner = (int)(sd.y >> 26);
+                    const float4 r0 = L.ray[2 * S.owner], r1 = L.ray[2 * S.owner + 1];
+                    S.q.o = {r0.x, r0.y, r0.z}; S.q.d = {r0.w, r1.x, r1.y}; S.a = r1.z;
+                    S.atm = S.a * (0.001f * 0.9999f - 1e-6f);
+                }
+                const unsigned nb = act ? min((unsigned)PB, min(S.seg_end, S.end) - S.cur) : 0u;   // (a batch stays within one owner's range)
+                const unsigned he0 = act ? S.base + S.cur : 0u;
+                const float4* __restrict__ hp = hot + he0;                            // (one address, the batch by immediate offsets)
+                float4 s4[PB];
+#pragma unroll
+                for (int k = 0; k < PB; ++k) s4[k] = hp[k];                           // (padded arrays: reading past a range is harmless, holding is not)
+                // the owner's best hit as of now
+                const float bt_now = __uint_as_float((unsigned)(L.key[S.owner] >> 32));
+                S.abt = __builtin_fmaf(S.a * bt_now, 1.0001f, 1e-6f * S.a);
+                if (act) { STAT(st, ST_TESTS, nb); STAT(st, ST_A_LANE_STEPS, 1); }
+                bool hold[PB]; float hb[PB], hd[PB];
+                bool anyhold = false;
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const float ocx = S.q.o.x - s4[k].x, ocy = S.q.o.y - s4[k].y, ocz = S.q.o.z - s4[k].z;
+                    const float b = ocx * S.q.d.x + ocy * S.q.d.y + ocz * S.q.d.z;
+                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[k].w;
+                    const float disc = b * b - S.a * c;
+                    // App. A.5: "near root beyond the best hit" (Lm) and "far root behind t_min" (M).  The two cannot both be
+                    // positive (Lm > 0 needs b + kb < -abt, M > 0 needs b - kb > -atm, and abt > atm): one test of the larger.
+                    // (the margins are fused here — one rounding less than the analysis allows for)
+                    const float ab = fabsf(b);
+                    const float Lm = __builtin_fmaf(ab, -1e-4f, -b) - S.abt, M = __builtin_fmaf(ab, -1e-4f, b) + S.atm;
+                    const float P = fmaxf(Lm, M);
+                    hold[k] = (unsigned)k < nb && disc > 0.0f && !(P > 0.0f && P * P > disc * 1.0003f);
+                    hb[k] = b; hd[k] = disc;
+                    anyhold = anyhold || hold[k];
+                }
+                if (__ballot(anyhold) != 0ull) {
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) {
+                        const unsigned long long hm = __ballot(hold[k]);
+                        if (hm != 0ull) {
+                            const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                            if (hold[k]) {
+                                STAT(st, ST_DISCPOS, 1);
+                                const uint4 ce = make_uint4(__float_as_uint(hb[k]), __float_as_uint(hd[k]), he0 + (unsigned)k, (unsigned)S.owner);
+                                if (slot < (unsigned)kWalkCand) L.cq[slot] = ce;
+                                else pool_candidate(T, s_nodes, L, ce STAT_PASS);
+                            }
+                            qn += (unsigned)__popcll(hm);
+                        }
+                    }
+                }
+                S.cur += nb;
+                if (qn >= (unsigned)RT_DENSE_DRAIN) pool_drain(T, s_nodes, L, lane, qn STAT_PASS);
+            }
+            pool_drain(T, s_nodes, L, lane, qn STAT_PASS);
+            const unsigned long long k = L.key[lane];
+            best_t = __uint_as_float((unsigned)(k >> 32)); best = (int)(unsigned)k;
+            const unsigned tmask = lane < 32 ? L.tie_lo : L.tie_hi;
+            if ((tmask >> (lane & 31)) & 1u) tie = true;
+        }
+        if (walking && best >= 0) walk_clip(W, A, best_t);
+        walking = walking && W.i != W.iend;
+        const int left = __popcll(__ballot(walking));
+        if (left == 0) break;
+        if (RT_QUORUM_DEN > 0 && nw0 >= RT_QUORUM_MIN && left * RT_QUORUM_DEN <= nw0) break;
+    }
+    W.walking = walking;
+}
+
 // hitTree (acceleration_structure.h:319-342): ground sphere first, then the tree.
 // The fast path's per-lane walk is bounded per call (RT_WALK_CAP phase-A iterations): a lane whose walk is not finished
 // comes back with ts.pending set and resumes on the next call with the same ray, while the lanes that are done go on to
@@ -1175,7 +1330,14 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             walk_pool<(COOPG >= 4 ? RT_QUORUM_SPARSE : RT_QUORUM_DENSE)>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
             if (walker) { ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
         }
-        else if (walker) walk_lanes<RT_BATCH_DENSE, RT_QUORUM_DENSE, RT_VOTE_DENSE>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
+        else if (RT_DENSE_POOL && COOPG == 2 && nw > 0) {
+            WalkLds& L = *((WalkLds*)(s_nodes + T.n_nodes * 3) + (threadIdx.x >> 6));
+            Walk Wl = ts.W; Wl.walking = walker && ts.W.walking;
+            float bt = walker ? closest : FLT_MAX; int bi = walker ? best : -1; bool tt = false;
+            walk_pool_dense<RT_QUORUM_DENSE>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
+            if (walker) { ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
+        }
+        else if (!(RT_DENSE_POOL && COOPG == 2) && walker) walk_lanes<RT_BATCH_DENSE, RT_QUORUM_DENSE, RT_VOTE_DENSE>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
         if (walker) {
             ts.pending = ts.W.walking;
             if (!ts.pending && ts.tie) { closest = ts.g_t; best = ts.g_id; slow = true; STAT(st, ST_TIE, 1); }
@@ -1869,12 +2031,14 @@ hipError_t launch_trace_list(const RenderArgs& A, unsigned blocks, const float* 
 // variant whose cooperative walk serves up to four rays side by side, rt_accel.h: coop_groups)
 static int render_variant(bool tree, int mode, const DevAccel& acc) {
     if (!tree) return 0;
-    return (mode == 0 && acc.enabled && acc.coop_groups >= 4) ? 4 : 1;
+    if (mode == 0 && acc.enabled) return acc.coop_groups >= 4 ? 4 : (RT_DENSE_POOL ? 2 : 1);
+    return 1;
 }
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
     switch (render_variant(tree, mode, acc)) {
         case 0: return mode == 0 ? "k_render<false,0,1>" : "k_render<false,1,1>";
         case 4: return "k_render<true,0,4>";
+        case 2: return "k_render<true,0,2>";
         default: return mode == 0 ? "k_render<true,0,1>" : "k_render<true,1,1>";
     }
 }
@@ -1899,10 +2063,12 @@ hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t s
     const int variant = render_variant(tree, mode, A.tree.acc);
     if (variant == 0) return launch_render_list(A, mode, st);
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
-    const size_t lds = tree_lds_bytes(A.tree.n_nodes, variant == 4);      // (the variant with the pooled walk)
-    const unsigned cap = variant == 4 ? resident_blocks(k_render<true, 0, 4>, lds) : mode == 0 ? resident_blocks(k_render<true, 0, 1>, lds) : resident_blocks(k_render<true, 1, 1>, lds);
+    const size_t lds = tree_lds_bytes(A.tree.n_nodes, variant == 4 || variant == 2);      // (the variants with a pooled walk)
+    const unsigned cap = variant == 4 ? resident_blocks(k_render<true, 0, 4>, lds) : variant == 2 ? resident_blocks(k_render<true, 0, 2>, lds)
+                       : mode == 0 ? resident_blocks(k_render<true, 0, 1>, lds) : resident_blocks(k_render<true, 1, 1>, lds);
     const unsigned blocks = need < cap ? need : cap;
     if (variant == 4) hipLaunchKernelGGL((k_render<true, 0, 4>), dim3(blocks), dim3(256), lds, st, A);
+    else if (variant == 2) hipLaunchKernelGGL((k_render<true, 0, 2>), dim3(blocks), dim3(256), lds, st, A);
     else if (mode == 0) hipLaunchKernelGGL((k_render<true, 0, 1>), dim3(blocks), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_render<true, 1, 1>), dim3(blocks), dim3(256), lds, st, A);
     return hipGetLastError();
