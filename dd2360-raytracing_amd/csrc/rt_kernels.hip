@@ -751,12 +751,10 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
                         const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
                         const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[k].w;
                         const float disc = b * b - a * c;
-                        const float kb = 1e-4f * fabsf(b);
-                        const float L = (-b - kb) - f_abt, M = (b - kb) + f_atm;
-                        const float dk = disc * 1.0003f;
-                        const bool beyond = L > 0.0f && L * L > dk;
-                        const bool behind = M > 0.0f && M * M > dk;
-                        if (disc > 0.0f && k < rem && !behind && !beyond) { kf = k; bf = b; df = disc; }
+                        const float ab = fabsf(b);                      // (L and M are never both positive: one test of the larger, see walk_pool)
+                        const float L = __builtin_fmaf(ab, -1e-4f, -b) - f_abt, M = __builtin_fmaf(ab, -1e-4f, b) + f_atm;
+                        const float P = fmaxf(L, M);
+                        if (disc > 0.0f && k < rem && !(P > 0.0f && P * P > disc * 1.0003f)) { kf = k; bf = b; df = disc; }
                     }
                     if (kf < RT_BATCH) {
                         p_b = bf; p_disc = df; p_e = e + kf;
@@ -1034,12 +1032,11 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
                     const float b = ocx * S.q.d.x + ocy * S.q.d.y + ocz * S.q.d.z;
                     const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[j].w;
                     const float disc = b * b - S.a * c;
-                    const float kb = 1e-4f * fabsf(b);
-                    const float Lm = (-b - kb) - S.abt, M = (b - kb) + S.atm;          // App. A.5
-                    const float dk = disc * 1.0003f;
-                    const bool beyond = Lm > 0.0f && Lm * Lm > dk;
-                    const bool behind = M > 0.0f && M * M > dk;
-                    hold[j] = act[j] && disc > 0.0f && !behind && !beyond;
+                    // App. A.5: near root beyond the best hit (Lm) / far root behind t_min (M); never both positive: one test of the larger
+                    const float ab = fabsf(b);
+                    const float Lm = __builtin_fmaf(ab, -1e-4f, -b) - S.abt, M = __builtin_fmaf(ab, -1e-4f, b) + S.atm;
+                    const float P = fmaxf(Lm, M);
+                    hold[j] = act[j] && disc > 0.0f && !(P > 0.0f && P * P > disc * 1.0003f);
                     hb[j] = b; hd[j] = disc;
                     anyhold = anyhold || hold[j];
                     if (act[j]) ++sp[j].cur;
@@ -2082,6 +2079,7 @@ hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const fl
     if (!tree) return launch_trace_list(A, blocks, rays, n, out, st);
     // the walk the render kernel would use for this tree (sparse grids: the pooled walk), so that per-ray parity checks cover it
     if (render_variant(true, 0, T.acc) == 4) hipLaunchKernelGGL((k_trace<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(T.n_nodes, true), st, A, rays, n, out);
+    else if (render_variant(true, 0, T.acc) == 2) hipLaunchKernelGGL((k_trace<true, 2>), dim3(blocks), dim3(256), tree_lds_bytes(T.n_nodes, true), st, A, rays, n, out);
     else hipLaunchKernelGGL((k_trace<true>), dim3(blocks), dim3(256), tree_lds_bytes(T.n_nodes), st, A, rays, n, out);
     return hipGetLastError();
 }

@@ -78,7 +78,7 @@ def test_float_hit_point_stays_within_the_inflated_ball():
 
 
 def test_walk_prefilter_never_rejects_an_acceptable_sphere():
-    """The square-root-free pre-filter of the grid walk (rt_kernels.hip, walk_lanes phase A) may only reject a
+    """The square-root-free pre-filter of the grid walk (rt_kernels.hip, walk_lanes / walk_pool / walk_pool_dense) may only reject a
     sphere whose float roots sphere::hit (sphere.h:24-43) would reject too.  Emulated in float32 numpy on cases built to sit ON the
     decision boundaries: best hit within +-1e-3 (relative) of the near root, far root within +-1e-3 of t_min."""
     rng = np.random.default_rng(5)
@@ -105,15 +105,25 @@ def test_walk_prefilter_never_rejects_an_acceptable_sphere():
         # the filter, as in the kernel (the fmaf is emulated in float64 and perturbed by an ulp either way below)
         abt0 = ((a * best_t).astype(F).astype(np.float64) * float(F(1.0001)) + (F(1e-6) * a).astype(F).astype(np.float64)).astype(F)
         atm = (a * F(F(0.001) * F(0.9999) - F(1e-6))).astype(F)
-        kb = (kap * np.abs(b)).astype(F)
-        M = ((b - kb).astype(F) + atm).astype(F)
+        # L = fma(|b|, -kap, -b) - abt, M = fma(|b|, -kap, b) + atm; they are never both positive, so the kernel tests the larger
+        # one only: P = max(L, M), reject if P > 0 and P^2 > 1.0003 disc.  The older form (kb rounded on its own, two tests) is
+        # checked alongside: it must decide alike up to the one rounding.
+        b64 = b.astype(np.float64); ab64 = np.abs(b64) * float(kap)
         dk = (disc * F(1.0003)).astype(F)
-        behind = (M > 0) & ((M * M).astype(F) > dk)
-        for abt in (abt0, np.nextafter(abt0, F(0)), np.nextafter(abt0, F(np.inf))):
-            L = ((-b - kb).astype(F) - abt).astype(F)
-            beyond = (L > 0) & ((L * L).astype(F) > dk)
-            reject = (disc > 0) & (beyond | behind)
-            assert not (reject & acceptable).any()
+        kb = (kap * np.abs(b)).astype(F)
+        for ulp in (0, -1, 1):
+            pre_l = (-b64 - ab64).astype(F); pre_m = (b64 - ab64).astype(F)
+            if ulp: pre_l = np.nextafter(pre_l, F(ulp * np.inf)); pre_m = np.nextafter(pre_m, F(ulp * np.inf))
+            M = (pre_m + atm).astype(F)
+            for abt in (abt0, np.nextafter(abt0, F(0)), np.nextafter(abt0, F(np.inf))):
+                L = (pre_l - abt).astype(F)
+                assert not ((L > 0) & (M > 0)).any()                                  # one test of the larger covers both
+                P = np.maximum(L, M)
+                reject = (disc > 0) & (P > 0) & ((P * P).astype(F) > dk)
+                assert not (reject & acceptable).any()
+        M0 = ((b - kb).astype(F) + atm).astype(F); L0 = ((-b - kb).astype(F) - abt0).astype(F)
+        reject0 = (disc > 0) & (((L0 > 0) & ((L0 * L0).astype(F) > dk)) | ((M0 > 0) & ((M0 * M0).astype(F) > dk)))
+        assert not (reject0 & acceptable).any()
     # the filter does something: most unacceptable boundary cases further than its margin are rejected
     assert (reject & ~acceptable).sum() > 0.2 * (~acceptable).sum()
 

@@ -90,4 +90,6 @@ frame(8000, 0.1, 30, 1200, 800, 32)
 frame(8000, 0.2, 30, 1200, 800, 16)
 frame(100000, 0.1, 320, 1920, 1080, 8)
 frame(10000, 0.05, 32, 800, 600, 32)
+frame(100000, 0.1, 320, 960, 540, 32)          # dense grid, long-chain pre-classification on: the pooled walk of dense grids
+frame(40000, 0.2, 100, 960, 540, 16)
 sys.exit(1 if bad else 0)
