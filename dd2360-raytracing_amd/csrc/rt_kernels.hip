@@ -1306,10 +1306,11 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         const bool walker = fast || (live && ts.pending);
         const int nw = __popcll(__ballot(walker));
         // the cooperative walk starts at a column boundary: not while a lane has a partly tested column
-        // dense grids (the plain variant): a wave with few walkers resolves them cooperatively, one ray at a time with lanes = spheres.
+        // the plain variant (per-lane walk): a wave with few walkers resolves them cooperatively, one ray at a time with lanes = spheres
+        // (the pooled variants serve a wave of one ray as well as a full one: with cooperative walks C5 723.7 against 723.9 ms).
         // Sparse grids (the pooled variant) pool the walks of any number of rays: measured with cooperative walks for <= 8 rays 20.41 ms,
         // <= 2: 20.27, none: 19.94 — and without that code the kernel fits four waves per SIMD (19.51 ms)
-        const bool coop = nw > 0 && nw <= (COOPG < 4 ? RT_COOP_MAX : RT_COOP_SPARSE) && __ballot(walker && ts.e < ts.e_end) == 0ull;
+        const bool coop = nw > 0 && nw <= (COOPG == 1 ? RT_COOP_MAX : COOPG == 2 ? 0 : RT_COOP_SPARSE) && __ballot(walker && ts.e < ts.e_end) == 0ull;
         if (coop) {
             const int lane_ = threadIdx.x & 63;
             unsigned long long todo = __ballot(walker && ts.W.walking);
@@ -1319,7 +1320,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS);
             }
         }
-        else if (COOPG >= 4 && nw > 0) {      // sparse grids only: on dense ones (C5: 37 entries per cell, ~100 per column) a round does not clip and filters against a stale best hit: 1754 ms with two columns per round, 1281 with one, against 817 for the per-lane walk
+        else if (COOPG >= 4 && nw > 0) {      // sparse grids (on dense ones — C5: 37 entries per cell, ~100 per column — this walk filters against a stale best hit: 1754 ms with two columns per round, 1281 with one, against 817 for the per-lane walk; they take walk_pool_dense)
             // every lane of the wave takes part: lanes without a walk of their own test other lanes' spheres
             WalkLds& L = *((WalkLds*)(s_nodes + T.n_nodes * 3) + (threadIdx.x >> 6));
             Walk Wl = ts.W; Wl.walking = walker && ts.W.walking;
