@@ -18,6 +18,7 @@ hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st);
+hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
 hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
 hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y, int nparts, hipStream_t st);
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st);
@@ -679,7 +680,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     A.scene = world->z->dev;
     A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
-    const bool sched = world->precision == RT_PRECISION_FP32 && mode == 0 && ns >= 4;
+    const bool sched = mode == 0 && ns >= 4;
     // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame: call rt_render
     // (or rt_render_ctx_reserve) once before capturing it into a hipGraph.
     if (sched && C.sched_tiles < A.n_local_tiles) {
@@ -694,7 +695,8 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     RT_TRY(launch_zero_counters(A.queue, 4, st));
     if (sched) {
         const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long
-        RT_TRY(launch_tile_order(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
+        if (world->precision == RT_PRECISION_FP16) RT_TRY(launch_tile_order_h(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
+        else RT_TRY(launch_tile_order(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
         A.order = C.d_order;
         if (classify) { A.long_flag = C.d_flags; A.long_list = C.d_long; }
     }

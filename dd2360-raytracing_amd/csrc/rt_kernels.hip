@@ -2041,6 +2041,17 @@ const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
     }
 }
 
+// after a pilot pass (k_tile_cost here, k_tile_cost_h in rt_kernels_fp16.hip) has written the tile costs and, behind the pixel flags,
+// the per-block counts: the long-chain list (if asked for) and the hand-out order of the tiles
+hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
+    if (flags) {
+        const unsigned char* pilot = flags + (size_t)A.n_local_tiles * 64;
+        hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, pilot, flags, long_list);
+    }
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const long long per_block = 4 * (64 / (16 * RT_PILOT_SAMPLES));       // a wave covers 4 / RT_PILOT_SAMPLES tiles
@@ -2051,9 +2062,7 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     if (tree && render_variant(true, 0, A.tree.acc) == 4 && RT_PILOT_POOL) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
     else if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
     else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
-    if (flags) hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, (const unsigned char*)pilot, flags, long_list);
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
-    return hipGetLastError();
+    return launch_select_and_order(A, cost, order, flags, long_list, st);
 }
 
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {

@@ -19,6 +19,12 @@ namespace h16 {
 
 #define RT_DEV static __device__ __forceinline__
 typedef half_t R;
+#ifndef RT_H16_LONG_PER_WAVE
+#define RT_H16_LONG_PER_WAVE 16        // pre-classified long chains per thin wave (k_render_h)
+#endif
+#ifndef RT_H16_PILOT_CAP
+#define RT_H16_PILOT_CAP 35            // bounces after which a pilot sample is cut
+#endif
 
 RT_DEV R rf(float f) { return half_t(f); }                 // real_t(float)
 RT_DEV R rd(double d) { return half_t((float)d); }         // real_t(double): double -> float -> half
@@ -571,11 +577,17 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
     WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? A.tree.n_nodes * 3 : 0)) + (threadIdx.x >> 6);     // this wave's area (TREE only)
     const int lane = threadIdx.x & 63;
     const long long n_slots = A.n_local_tiles * 64;
-    const long long first_free = (long long)gridDim.x * 256;
+    const long long first_free = 0;                                // every slot is handed out by the work counter
     const int ns = (MODE == 0) ? A.ns : 1;
     const Cam cam = load_camera(A.scene.cam);
+    // scheduling as in k_render (rt_kernels.hip): tiles in the pilot pass's longest-first order, slots interleaved over blocks of 64
+    // tiles, pre-classified long chains first, RT_H16_LONG_PER_WAVE to a wave that does not refill its other lanes while one is alive
+    const unsigned int n_long_raw = A.long_list ? A.queue[2] : 0u;
+    const bool use_long = n_long_raw != 0u && (long long)n_long_raw * 64 <= n_slots;
+    const unsigned int n_long = use_long ? n_long_raw : 0u;
+    bool is_long = false, long_done = false, thin = false, retired = false;
 
-    long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    long long slot = 0;
     int i = 0, j = 0; long long idx = 0;
     Rng s = {0, 0, 0, 0, 0, 0};
     V col = {ri(0), ri(0), ri(0)};
@@ -584,23 +596,48 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
     int sample = 0, depth = 0;
     bool live = false;
 
+    auto start_pixel = [&]() {
+        const rt_rand_state* st = A.rand_state + idx;
+        s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
+        col = {ri(0), ri(0), ri(0)}; att = {rd(1.0), rd(1.0), rd(1.0)}; sample = 0; depth = 0;
+        r = primary_ray(cam, i, j, A.max_x, A.max_y, s);
+    };
     auto begin_pixel = [&]() {
-        live = false;
+        live = false; is_long = false;
         while (slot < n_slots) {
-            const long long local_tile = slot >> 6;
-            const int l = (int)(slot & 63);
+            // consecutive slots are the same pixel position of 64 different tiles (in hand-out order): the pixels of a tile never travel together
+            const long long blk = slot >> 12;
+            const long long tiles_in_blk = (A.n_local_tiles - blk * 64) < 64 ? (A.n_local_tiles - blk * 64) : 64;
+            const long long within = slot & 4095;
+            const long long rank = blk * 64 + within % tiles_in_blk;
+            const int l = (int)(within / tiles_in_blk);
+            const long long local_tile = A.order ? (long long)A.order[rank] : rank;
             const long long tile = A.part + local_tile * A.nparts;
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
-            if (i < A.max_x && j < A.max_y) { idx = (A.nparts == 1) ? (long long)j * A.max_x + i : slot; live = true; break; }
+            const bool taken = use_long && A.long_flag[local_tile * 64 + l];      // long chains are handed out separately
+            if (i < A.max_x && j < A.max_y && !taken) { idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l; live = true; break; }
             slot = first_free + (long long)atomicAdd(A.queue, 1u);
         }
-        if (live) {
-            const rt_rand_state* st = A.rand_state + idx;
-            s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
-            col = {ri(0), ri(0), ri(0)}; att = {rd(1.0), rd(1.0), rd(1.0)}; sample = 0; depth = 0;
-            r = primary_ray(cam, i, j, A.max_x, A.max_y, s);
-        }
+        if (!live) retired = true;
+        if (live) start_pixel();
+    };
+    // the next pre-classified long chain (lanes 0..RT_H16_LONG_PER_WAVE-1), strided through the list as in k_render
+    auto begin_long_pixel = [&]() -> bool {
+        if (!use_long || long_done) return false;
+        const unsigned int h = atomicAdd(A.queue + 3, 1u);
+        if (h >= n_long) { long_done = true; return false; }
+        const unsigned int stride = n_long % 257u ? 257u : (n_long % 263u ? 263u : 269u);
+        const long long pid = (long long)A.long_list[(unsigned int)(((unsigned long long)h * stride) % n_long)];
+        const long long local_tile = pid >> 6;
+        const int l = (int)(pid & 63);
+        const long long tile = A.part + local_tile * A.nparts;
+        const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+        i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
+        idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
+        live = true; is_long = true;
+        start_pixel();
+        return true;
     };
     auto end_pixel = [&]() {
         rt_rand_state* st = A.rand_state + idx;
@@ -618,10 +655,17 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
             }
         }
     };
-    if (ns > 0) begin_pixel();
+    if (ns > 0) {
+        if (lane < RT_H16_LONG_PER_WAVE) begin_long_pixel();
+        if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
+        else { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+    }
     unsigned long long tk0 = H16_TICK(); (void)tk0;
 
-    while (__ballot(live) != 0ull) {
+    while (true) {
+        if (thin && __ballot(live && is_long) == 0ull) { thin = false; __builtin_amdgcn_s_setprio(0); }      // its chains have ended: refill
+        if (!thin && !live && !retired && ns > 0) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
+        if (__ballot(live) == 0ull) break;
         const R a = vdot(r.d, r.d);
         R closest = rf(FLT_MAX); int best = -1;                              // real_t(FLT_MAX) = +inf in binary16
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, *wl, r, a, live, closest, best);
@@ -641,13 +685,69 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
                 if (sample < ns) r = primary_ray(cam, i, j, A.max_x, A.max_y, s);
                 else {
                     end_pixel();
-                    slot = first_free + (long long)atomicAdd(A.queue, 1u);
-                    begin_pixel();
+                    live = false; is_long = false;
+                    if (lane < RT_H16_LONG_PER_WAVE && begin_long_pixel()) { /* the next long chain */ }
+                    else if (!thin) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
                 }
             }
         }
     }
     H16_ADD(3, tk0);                                                 // whole loop
+}
+
+// The pilot pass of the scheduling (k_tile_cost of rt_kernels.hip in binary16): two samples per 2x2 pixel block on a private RNG
+// stream, in adjacent lanes, cut at RT_H16_PILOT_CAP bounces; only the bounce counts are kept — per tile for the hand-out order,
+// per block for k_long_select.  Changes WHEN a pixel is rendered, never the pixel.
+template <bool TREE>
+__global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_tile_cost_h(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ pilot) {
+    extern __shared__ float4 s_nodes[];
+    if (TREE) {
+        const int n4 = A.tree.n_nodes * 3;
+        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
+        __syncthreads();
+    }
+    WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? A.tree.n_nodes * 3 : 0)) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const Cam cam = load_camera(A.scene.cam);
+    // a wave covers two tiles: 16 blocks x 2 samples each
+    const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + lane / 32;
+    const bool tile_ok = local_tile < A.n_local_tiles;
+    const long long tile = A.part + (tile_ok ? local_tile : 0) * A.nparts;
+    const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+    const int sub = (lane % 32) / 2, smp = lane % 2;
+    const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
+    const int i = tx * 8 + lx, j = ty * 8 + ly;
+    const bool inside = tile_ok && (i < A.max_x) && (j < A.max_y);
+    // a private stream: any state that is not all zero will do (this is not curand_init; nothing is compared with it)
+    Rng ps;
+    {
+        unsigned long long z = 0x5deece66dull + (unsigned long long)((long long)j * A.max_x + i) * 0x9e3779b97f4a7c15ull + (unsigned long long)smp * 0xbf58476d1ce4e5b9ull;
+        auto mix = [&]() { z += 0x9e3779b97f4a7c15ull; unsigned long long x = z; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return (uint32_t)((x ^ (x >> 31)) >> 16); };
+        ps.v0 = mix() | 1u; ps.v1 = mix(); ps.v2 = mix(); ps.v3 = mix(); ps.v4 = mix(); ps.d = mix();
+    }
+    V att = {rd(1.0), rd(1.0), rd(1.0)};
+    Ray r; r.o = {ri(0), ri(0), ri(0)}; r.d = {ri(0), ri(1), ri(0)};
+    bool live = inside;
+    if (live) r = primary_ray(cam, i, j, A.max_x, A.max_y, ps);
+    int bounces = 0;
+    while (__ballot(live) != 0ull) {
+        const R a = vdot(r.d, r.d);
+        R closest = rf(FLT_MAX); int best = -1;
+        if (TREE) closest_tree(A.scene, A.tree, s_nodes, *wl, r, a, live, closest, best);
+        else closest_list(A.scene, r, a, closest, best);
+        if (live) {
+            ++bounces;
+            bool done = true;
+            if (best >= 0) { const bool cont = scatter(A.scene, best, closest, r, att, ps); done = !cont || bounces >= RT_H16_PILOT_CAP; }
+            if (done) live = false;
+        }
+    }
+    int pix = inside ? bounces : 0;
+    pix += __shfl_xor(pix, 1);                                      // the block's two samples
+    if (pilot && tile_ok && smp == 0) pilot[local_tile * 16 + sub] = (unsigned char)(pix < 255 ? pix : 255);
+    int w = inside ? bounces : 0;
+    for (int off = 16; off > 0; off >>= 1) w += __shfl_xor(w, off);                      // the tile's 16 blocks x 2 samples
+    if (lane % 32 == 0 && tile_ok) cost[local_tile] = w * 4;
 }
 
 template <bool TREE>
@@ -706,6 +806,19 @@ static unsigned resident_blocks_h(const void* kernel, size_t lds) {
 
 const char* render_kernel_name_h(bool tree, int mode) {
     return tree ? (mode == 0 ? "k_render_h<true,0>" : "k_render_h<true,1>") : (mode == 0 ? "k_render_h<false,0>" : "k_render_h<false,1>");
+}
+
+hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);   // rt_kernels.hip
+
+// the scheduling pre-pass of a binary16 render: pilot pass in binary16, then the precision-independent selection and ordering
+hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
+    if (A.n_local_tiles <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((A.n_local_tiles + 7) / 8);                 // a wave covers two tiles
+    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) + 4 * sizeof(h16::WaveLds) : 0;
+    unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
+    if (tree) hipLaunchKernelGGL((h16::k_tile_cost_h<true>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
+    else hipLaunchKernelGGL((h16::k_tile_cost_h<false>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
+    return launch_select_and_order(A, cost, order, flags, long_list, st);
 }
 
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
