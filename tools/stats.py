@@ -12,7 +12,7 @@ L.rt_debug_stats.argtypes = [C.c_void_p, C.c_int]
 names = ["rays", "fast", "slow", "tie", "cols", "tests", "discpos", "offers", "elig", "elig_nodes", "A_iters_wave", "B_rounds_wave",
          "loop_iters_wave", "A_lane_steps", "B_lanes", "waves", "live_ge56", "live_32_55", "live_8_31", "live_lt8", "switches"]
 n, nx, ny, ns, spl = (int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (10000, 1200, 800, 8, 32)))
-W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload()
+W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload() if spl > 0 else None          # spl 0: the hitable_list path (through its grid)
 st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny)
 buf = (C.c_ulonglong * 64)()
 rt.render_init(nx, ny, st); torch.cuda.synchronize()
@@ -22,7 +22,7 @@ L.rt_debug_stats(buf, 1)
 raw = list(buf)
 v = dict(zip(names, raw))
 rays = max(1, v["rays"]); samples = nx * ny * ns; waves = max(1, v["waves"])
-print("accel", O.accel_info())
+print("accel", O.accel_info() if O is not None else W.list_accel_info())
 print("samples %d rays/sample %.3f fast %.4f slow %.5f ties %d" % (samples, rays / samples, v["fast"] / rays, v["slow"] / rays, v["tie"]))
 for k in ("cols", "tests", "discpos", "offers", "elig", "elig_nodes", "A_lane_steps", "B_lanes"):
     print("  %-14s %8.3f per ray" % (k, v[k] / rays))
