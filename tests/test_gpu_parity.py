@@ -387,6 +387,44 @@ def test_fp16_progressive_and_partition(rt, cuda):
     assert torch.equal(full.view(torch.int16), whole.view(torch.int16))
 
 
+@pytest.mark.parametrize("nparts", [1, 3])
+def test_fp16_scheduled_render_on_ragged_and_partitioned_frames(rt, cuda, nparts):
+    """USE_FP16 from 16 samples per pixel on: pilot pass in binary16 (k_tile_cost_h), longest-first order, interleaved slots, long
+    chains first in thin waves.  A ragged frame, whole and in three parts: binary16 framebuffer and RNG state bit-equal to the fp16
+    oracle, and chains were pre-classified."""
+    torch = cuda
+    nx, ny, ns, n = 403, 301, 16, 500
+    W = rt.World(n, nx, ny, precision=rt.FP16)
+    O = rt.Octree(W, 30)
+    ref, ref_st = OracleScene(n, nx, ny, fp16=True, use_octree=True, spl=30).render(ns, nthreads=8)
+    per = rt.part_pixels(nx, ny, rt.Partition(0, nparts))
+    parts = torch.zeros(nparts * per * 3, dtype=torch.float16, device="cuda")
+    n_long = 0
+    for p in range(nparts):
+        part = rt.Partition(p, nparts)
+        st = rt.alloc_rand_state(nx, ny, part)
+        fb = rt.alloc_fb(nx, ny, part, precision=rt.FP16)
+        rt.render_init(nx, ny, st, part)
+        rt.render(fb, nx, ny, ns, W, st, O, part)
+        torch.cuda.synchronize()
+        c = W.render_counters()
+        assert c["long_handles"] >= c["long_chains"]
+        n_long += c["long_chains"]
+        if nparts == 1:
+            nan = np.isnan(ref)
+            assert np.array_equal(half_bits(fb).reshape(ny, nx, 3)[~nan], f32_to_half_bits(ref)[~nan])
+            assert np.array_equal(st.cpu().numpy().view(np.uint32).reshape(-1, 12)[:, :6], ref_st[:, :6])
+        else:
+            parts[p * per * 3: p * per * 3 + fb.numel()] = fb
+    if nparts > 1:
+        full = torch.zeros(nx * ny * 3, dtype=torch.float16, device="cuda")
+        rt.assemble(full, parts, nx, ny, nparts, precision=rt.FP16)
+        torch.cuda.synchronize()
+        nan = np.isnan(ref)
+        assert np.array_equal(half_bits(full).reshape(ny, nx, 3)[~nan], f32_to_half_bits(ref)[~nan])
+    assert 0 < n_long <= nx * ny // 64, n_long
+
+
 def test_fp16_c4_properties_and_psnr(rt, cuda):
     """BASELINE config 4 geometry (1200x800, N=10000 octree SPL 32, fp16) at 8 spp: deterministic, sampled rows equal
     the oracle, and the fp16-vs-fp32 distance is in the band the reference reports (PSNR 12.4 dB, evaluations.ipynb:1076)."""
