@@ -828,6 +828,10 @@ RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, f
 #ifndef RT_POOL_SPANS
 #define RT_POOL_SPANS 1
 #endif
+#ifndef RT_POOL_COLS_THIN
+#define RT_POOL_COLS_THIN 4
+#endif
+static_assert(RT_POOL_COLS_THIN >= RT_POOL_COLS, "a thin round takes at least as many columns as a full one");
 constexpr int kWalkPool = 64 * RT_POOL_COLS;                  // segments per wave and round
 constexpr int kWalkCand = 128;
 struct WalkLds {
@@ -924,11 +928,14 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
         if (lane == 0) { L.tie_lo = 0u; L.tie_hi = 0u; }
         walk_sync();
         // ---- phase 1: the entry ranges of the next RT_POOL_COLS columns of every walking lane (their cell-start loads in flight together)
-        int e0[RT_POOL_COLS], e1[RT_POOL_COLS];
+        // (a wave with few walkers — a thin wave's chains, the frame's critical path — takes RT_POOL_COLS_THIN columns per round: as
+        // many cell-start loads in flight, fewer rounds and their dependent round trips; the pool holds 64 x RT_POOL_COLS ranges)
+        const int cols_now = nw0 * RT_POOL_COLS_THIN <= kWalkPool ? RT_POOL_COLS_THIN : RT_POOL_COLS;
+        int e0[RT_POOL_COLS_THIN], e1[RT_POOL_COLS_THIN];
 #pragma unroll
-        for (int c = 0; c < RT_POOL_COLS; ++c) {
+        for (int c = 0; c < RT_POOL_COLS_THIN; ++c) {
             e0[c] = 0; e1[c] = 0;
-            if (walking && W.i != W.iend) {
+            if (c < cols_now && walking && W.i != W.iend) {
                 STAT(st, ST_COLS, 1);
                 const float u0 = W.on_c + ((float)W.i - W.om_c) * W.slope, u1 = u0 + W.slope;
                 const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
@@ -942,7 +949,8 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
         }
         unsigned n_seg = 0u;                                         // (<= 64 x RT_POOL_COLS: the pool cannot overflow)
 #pragma unroll
-        for (int c = 0; c < RT_POOL_COLS; ++c) {
+        for (int c = 0; c < RT_POOL_COLS_THIN; ++c) {
+            if (c >= RT_POOL_COLS && c >= cols_now) break;          // (wave-uniform)
             const bool has = e1[c] > e0[c];
             const unsigned long long m = __ballot(has);
             if (has) {
