@@ -45,6 +45,7 @@ struct AccelHost {
 
 // constants of the exactness argument
 constexpr double kZone = 24.0;          // near zone: |o - (0,1,0)| <= kZone
+// (kRootHalfXZ, kCellXZ, kCellY and their float forms: rt_device.h)
 constexpr double kCentreBound = 17.5;   // grid spheres have |c - (0,1,0)| <= this (root box grown by the radius)
 constexpr double kSlack = 2e-3;         // rasterisation slack (absorbs float error of the walk, ~1e-5)
 // "brick" of a sphere = the box of level-3 cells [ix0..ix1] x [iy0..iy1] x [iz0..iz1] when EVERY cell of that box stores the
@@ -86,7 +87,7 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     A.cellnode.assign(512, -1);
     for (size_t k = 0; k < nodes.size() && !list_mode; ++k) {
         if (nodes[k].count <= 0) continue;
-        const int ix = (int)std::lround((nodes[k].lo[0] + 11.0) / 2.75), iy = (int)std::lround(nodes[k].lo[1] / 0.25), iz = (int)std::lround((nodes[k].lo[2] + 11.0) / 2.75);
+        const int ix = (int)std::lround((nodes[k].lo[0] + kRootHalfXZ) / kCellXZ), iy = (int)std::lround(nodes[k].lo[1] / kCellY), iz = (int)std::lround((nodes[k].lo[2] + kRootHalfXZ) / kCellXZ);
         if (ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) A.cellnode[ix * 64 + iy * 8 + iz] = (int32_t)k;
     }
     // membership bitmaps (one 512-bit row per sphere that is stored in more than one node)
@@ -150,13 +151,13 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         // dense scenes (a sphere covers ~4 cells of size 2R': more than 8 entries per cell expected) take cells of 1.4 R':
         // tests per ray go with the cell size, columns per ray against it (C5, 37 per cell: 129.5 -> 122.4 ms at 0.7, 125.4 at
         // 0.5; C3, 3.6 per cell: 22.7 -> 23.2 ms at 0.7, so sparse scenes keep 2R')
-        const double g = std::ceil(2.0 * (11.0 + 5.0 * h) / h);
+        const double g = std::ceil(2.0 * (kRootHalfXZ + 5.0 * h) / h);
         if (4.0 * (double)radii.size() > 8.0 * g * g) h = std::max(0.05, kDenseCell * h);
     }
     const double Rlim = 1.5 * h;                               // spheres with R' above this go to the large list
     // extent: the reference's root box in x and z (every tree sphere's centre lies in it, grown by its radius); a list may
     // reach further out — as far as the centre bound of the exactness argument lets the grid follow
-    double reach = 11.0;
+    double reach = kRootHalfXZ;
     if (list_mode)
         for (int s = 0; s < n_world; ++s) {
             if (!in_tree[s]) continue;

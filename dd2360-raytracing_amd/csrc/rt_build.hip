@@ -597,9 +597,9 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     const double rmed = std::sqrt((double)med_r2);
     double h = 2.0 * accel_Rp(rmed * rmed);
     h = std::min(1.0, std::max(0.05, h));
-    { const double g = std::ceil(2.0 * (11.0 + 5.0 * h) / h); if (4.0 * (double)in_tree > 8.0 * g * g) h = std::max(0.05, kDenseCell * h); }
+    { const double g = std::ceil(2.0 * (kRootHalfXZ + 5.0 * h) / h); if (4.0 * (double)in_tree > 8.0 * g * g) h = std::max(0.05, kDenseCell * h); }
     GridParams P; P.h = h; P.Rlim = 1.5 * h;
-    const double half = 11.0 + 2.0 * P.Rlim + 2.0 * h;
+    const double half = kRootHalfXZ + 2.0 * P.Rlim + 2.0 * h;
     P.G = (int)std::ceil(2.0 * half / h); P.g0 = -half;
     const int G = P.G;
     hipLaunchKernelGGL(k_classify, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int32_t*)memb_start, (const float4*)hot_of, P, is_large, nreg, range, C);

@@ -6,6 +6,15 @@
 
 namespace rt {
 
+// The reference's root box is fixed: (-11, 0, -11)-(11, 2, 11) (acceleration_structure.h:203).  Halved three times it gives 8 x 8 x 8
+// level-3 cells of kCellXZ x kCellY x kCellXZ; everything that depends on that geometry — the cell of a hit point, the bricks' cell
+// coordinates, the grid's reach — is written in terms of these constants, here, in the kernels and in the device build.
+constexpr double kRootHalfXZ = 11.0;            // the box spans [-kRootHalfXZ, kRootHalfXZ] in x and z, [0, 8 kCellY] in y
+constexpr double kCellXZ = 2.0 * kRootHalfXZ / 8.0, kCellY = 0.25;
+constexpr float kRootHalfXZf = (float)kRootHalfXZ, kInvCellXZf = 1.0f / 2.75f, kInvCellYf = 4.0f;
+static_assert(kCellXZ == 2.75 && 1.0 / kCellY == 4.0, "level-3 cells of the reference's root box");
+
+
 // One node of the traversal copy of the Octree, in depth-first pre-order (children in index order, the visit
 // order of traverseTree, acceleration_structure.h:276-304).  48 bytes = 3 x 16 B so a lane fetches it with
 // three ds_read_b128 from LDS.

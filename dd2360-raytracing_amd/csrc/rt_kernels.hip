@@ -419,7 +419,7 @@ RT_DEV bool eligible(const float4* s_nodes, const RayF& r, float cand, int spher
     {
         const int row = T.acc.bits_index[sphere];
         const float px = r.o.x + cand * r.d.x, py = r.o.y + cand * r.d.y, pz = r.o.z + cand * r.d.z;
-        const int ix = (int)floorf((px + 11.0f) * (1.0f / 2.75f)), iy = (int)floorf(py * 4.0f), iz = (int)floorf((pz + 11.0f) * (1.0f / 2.75f));
+        const int ix = (int)floorf((px + kRootHalfXZf) * kInvCellXZf), iy = (int)floorf(py * kInvCellYf), iz = (int)floorf((pz + kRootHalfXZf) * kInvCellXZf);
         if (row >= 0 && ix >= 0 && ix < 8 && iy >= 0 && iy < 8 && iz >= 0 && iz < 8) {
             const int cell = ix * 64 + iy * 8 + iz;
             const int node = T.acc.cellnode[cell];
@@ -449,9 +449,9 @@ RT_DEV bool eligible(const float4* s_nodes, const RayF& r, float cand, int spher
 // planes, so the cells' intervals tile the brick's without gaps): that node passes the reference's slab test, and with it
 // its ancestors — no division needed.  Approximate arithmetic is fine here: its error is part of the 1e-5.
 RT_DEV bool in_brick(const RayF& r, float cand, const float4 blo, const float4 bhi) {
-    const float ux = __builtin_fmaf(__builtin_fmaf(cand, r.d.x, r.o.x), 1.0f / 2.75f, 4.0f);
-    const float uy = __builtin_fmaf(cand, r.d.y, r.o.y) * 4.0f;
-    const float uz = __builtin_fmaf(__builtin_fmaf(cand, r.d.z, r.o.z), 1.0f / 2.75f, 4.0f);
+    const float ux = __builtin_fmaf(__builtin_fmaf(cand, r.d.x, r.o.x), kInvCellXZf, 4.0f);      // (x + 11) / 2.75 = x / 2.75 + 4: cell coordinates 0..8
+    const float uy = __builtin_fmaf(cand, r.d.y, r.o.y) * kInvCellYf;
+    const float uz = __builtin_fmaf(__builtin_fmaf(cand, r.d.z, r.o.z), kInvCellXZf, 4.0f);
     return ux > blo.x && ux < bhi.x && uy > blo.y && uy < bhi.y && uz > blo.z && uz < bhi.z;
 }
 
