@@ -76,6 +76,33 @@ def test_trace_hit_records(rt, cuda, n, spl, tree):
     assert np.array_equal(bits(got["normal"]), bits(ref["normal"]))
 
 
+def test_trace_hit_records_on_a_dense_grid(rt, cuda):
+    """C5's world (100 000 spheres, SPHERES_PER_LEAF 320: ~30 entries per grid cell) takes the pooled walk of dense grids
+    (walk_pool_dense through k_trace<true,2>; the kernel name says which variant the library chose): hit records bit-identical to the
+    oracle's hitTree, and to the library's own reference scan."""
+    torch = cuda
+    n, spl, nrays = 100000, 320, 40_000
+    rays = random_rays(nrays, 99)
+    W = rt.World(n, 3840, 2160)
+    O = rt.Octree(W, spl)
+    assert rt.render_kernel_name(W, O, 0) == "k_render<true,0,2>"
+    d_rays = torch.from_numpy(rays).cuda()
+    outs = []
+    for mode in (rt.TRAVERSAL_FAST, rt.TRAVERSAL_REFERENCE):
+        O.set_traversal(mode)
+        d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+        rt.trace_rays(W, O, d_rays, nrays, d_out)
+        torch.cuda.synchronize()
+        outs.append(d_out.cpu().numpy().view(rt.hit_record_dtype))
+    ref = OracleScene(n, 3840, 2160, use_octree=True, spl=spl).trace(rays, mode=2)
+    for got in outs:
+        assert np.array_equal(got["sphere"], ref["sphere"])
+        assert np.array_equal(bits(got["t"]), bits(ref["t"]))
+        assert np.array_equal(bits(got["p"]), bits(ref["p"]))
+        assert np.array_equal(bits(got["normal"]), bits(ref["normal"]))
+    assert ref["hit"].sum() > nrays // 20
+
+
 @pytest.mark.parametrize("n,nx,ny,ns,tree,spl", [
     (22, 64, 36, 4, False, 30), (22, 64, 36, 4, True, 30),
     (500, 64, 36, 4, False, 30), (500, 61, 35, 3, True, 30),      # ragged: not a multiple of the 8x8 tile
