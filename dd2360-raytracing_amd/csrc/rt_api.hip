@@ -279,15 +279,19 @@ static int world_upload(const rt_world* W) {
     rt_world::Lazy& Z = *W->z;
     if (Z.uploaded) return 0;
     int rc;
+    std::vector<float4> shade(2 * (size_t)W->n);
+    std::vector<uint8_t> kind8((size_t)W->n);
+    for (int i = 0; i < W->n; ++i) { shade[2 * (size_t)i] = W->h_geom[i]; shade[2 * (size_t)i + 1] = W->h_mat[i]; kind8[i] = (uint8_t)W->h_kind[i]; }
     if ((rc = upload(W->h_hot, &Z.d_list_hot)) || (rc = upload(W->h_ids, &Z.d_list_id)) || (rc = upload(W->h_geom, &Z.d_geom)) ||
-        (rc = upload(W->h_mat, &Z.d_mat)) || (rc = upload(W->h_kind, &Z.d_kind))) {
-        void* bufs[5] = {Z.d_list_hot, Z.d_list_id, Z.d_geom, Z.d_mat, Z.d_kind};       // nothing half-made stays behind
-        (void)free_all(bufs, 5);
-        Z.d_list_hot = Z.d_list_id = Z.d_geom = Z.d_mat = Z.d_kind = nullptr;
+        (rc = upload(W->h_mat, &Z.d_mat)) || (rc = upload(W->h_kind, &Z.d_kind)) || (rc = upload(shade, &Z.d_shade)) || (rc = upload(kind8, &Z.d_kind8))) {
+        void* bufs[7] = {Z.d_list_hot, Z.d_list_id, Z.d_geom, Z.d_mat, Z.d_kind, Z.d_shade, Z.d_kind8};       // nothing half-made stays behind
+        (void)free_all(bufs, 7);
+        Z.d_list_hot = Z.d_list_id = Z.d_geom = Z.d_mat = Z.d_kind = Z.d_shade = Z.d_kind8 = nullptr;
         return rc;
     }
     Z.dev.list_hot = (const float4*)Z.d_list_hot; Z.dev.list_id = (const int32_t*)Z.d_list_id;
     Z.dev.geom = (const float4*)Z.d_geom; Z.dev.mat = (const float4*)Z.d_mat; Z.dev.kind = (const int32_t*)Z.d_kind;
+    Z.dev.shade = (const float4*)Z.d_shade; Z.dev.kind8 = (const uint8_t*)Z.d_kind8;
     if ((rc = ctx_prepare(Z.ctx))) return rc;
     if (Z.list_tree && (rc = rt_octree_upload(Z.list_tree))) return rc;      // (if it has been built already)
     Z.uploaded = true;
@@ -301,8 +305,8 @@ int rt_free_world(rt_world* W) {
     if (W->z) {
         rt_world::Lazy& Z = *W->z;
         if (Z.list_tree) { rc = rt_free_octree(Z.list_tree); Z.list_tree = nullptr; }
-        void* bufs[5] = {Z.d_list_hot, Z.d_list_id, Z.d_geom, Z.d_mat, Z.d_kind};
-        const int r2 = free_all(bufs, 5); if (!rc) rc = r2;
+        void* bufs[7] = {Z.d_list_hot, Z.d_list_id, Z.d_geom, Z.d_mat, Z.d_kind, Z.d_shade, Z.d_kind8};
+        const int r2 = free_all(bufs, 7); if (!rc) rc = r2;
         const int r3 = ctx_release(Z.ctx); if (!rc) rc = r3;
         delete W->z;
     }

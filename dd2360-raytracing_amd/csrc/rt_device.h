@@ -36,6 +36,8 @@ struct DevScene {
     const float4* geom;       // [n] (cx, cy, cz, radius)
     const float4* mat;        // [n] (albedo r,g,b, param)
     const int32_t* kind;      // [n] RT_MAT_*
+    const float4* shade;      // [2n] what a hit needs, side by side: geom[i], mat[i] — one 32-byte record, one cache line per hit
+    const uint8_t* kind8;     // [n] RT_MAT_* as bytes (10 KB at C3: stays in the vector L1)
     int32_t n, n_list;
     int32_t ground_valid;     // world list slot 0 is hittable (it is tested first by hitTree)
     rt_camera cam;

@@ -41,6 +41,7 @@ struct rt_world {
         bool uploaded = false;
         DevScene dev{};
         void* d_list_hot = nullptr; void* d_list_id = nullptr; void* d_geom = nullptr; void* d_mat = nullptr; void* d_kind = nullptr;
+        void* d_shade = nullptr; void* d_kind8 = nullptr;        // geom and mat interleaved, kind as bytes (DevScene::shade / kind8)
         // hitable_list::hit through the candidate grid: the list as a one-node "tree" (fp32 only; null = plain scan)
         rt_octree* list_tree = nullptr; bool list_tree_tried = false;
         rt_render_ctx ctx;                      // the context rt_render / rt_render_progressive use

@@ -1392,9 +1392,9 @@ RT_DEV RayF primary_ray(const rt_camera& c, int i, int j, int max_x, int max_y, 
 
 // material::scatter for the sphere that was hit.  Returns false when the path is absorbed (metal, material.h:72).
 RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rng& s) {
-    const float4 g = S.geom[sphere];
-    const float4 m = S.mat[sphere];
-    const int kind = S.kind[sphere];
+    const float4 g = S.shade[2 * sphere];
+    const float4 m = S.shade[2 * sphere + 1];
+    const int kind = S.kind8[sphere];
     V3 p, n;
     p.x = r.o.x + t * r.d.x; p.y = r.o.y + t * r.d.y; p.z = r.o.z + t * r.d.z;            // ray.h:13
     n.x = (p.x - g.x) / g.w; n.y = (p.y - g.y) / g.w; n.z = (p.z - g.z) / g.w;            // sphere.h:29

@@ -502,9 +502,9 @@ RT_DEV Ray primary_ray(const Cam& c, int i, int j, int max_x, int max_y, Rng& s)
 
 // material::scatter (material.h:55-113); false = absorbed
 RT_DEV bool scatter(const DevScene& S, int sphere, R t, Ray& r, V& att, Rng& s) {
-    const float4 g = S.geom[sphere];
-    const float4 m = S.mat[sphere];
-    const int kind = S.kind[sphere];
+    const float4 g = S.shade[2 * sphere];
+    const float4 m = S.shade[2 * sphere + 1];
+    const int kind = S.kind8[sphere];
     const V c = {rf(g.x), rf(g.y), rf(g.z)};
     const V p = vadd(r.o, vscale(t, r.d));                                  // ray.h:13
     const V n = vdiv(vsub(p, c), rf(g.w));                                  // sphere.h:29
