@@ -50,7 +50,7 @@ namespace rt {
 #endif
 // a pixel averaging at least this many bounces per sample is a long chain (the scene average is ~2.7)
 #ifndef RT_LONG_RATE
-#define RT_LONG_RATE 20
+#define RT_LONG_RATE 14
 #endif
 // at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
 #ifndef RT_THIN_CAP_DEN
@@ -100,6 +100,9 @@ namespace rt {
 // long chains started per thin wave
 #ifndef RT_GROUND_SHORT
 #define RT_GROUND_SHORT 1      // skip the exact ground test for rays that leave the ground behind (exact, see closest_tree)
+#endif
+#ifndef RT_LONG_CHECK
+#define RT_LONG_CHECK 4         // a pixel's bounce rate is looked at every so many samples (a power of two; 8 with rate 20: C3 17.85 ms, 4 / 20: 17.55, 4 / 16: 17.2, 4 / 14: 16.93, 4 / 13: 17.17, 4 / 12: 17.6, 8 / 14: 17.5, 2 / 20: 17.9)
 #endif
 #ifndef RT_LONG_STRIDE
 #define RT_LONG_STRIDE 1
@@ -1718,7 +1721,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                 if (sample < ns) {
                     { const RenderArgs& C = *cold_args(); r = primary_ray(C.scene.cam, i, j, C.max_x, C.max_y, s); }
                     // classify after every 4th sample while enough of the chain is left for it to matter
-                    if ((sample & 7) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_LONG_RATE * sample)) {
+                    if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_LONG_RATE * sample)) {
 #ifdef RT_STATS
                         if (!is_long) ++dbg_long;
 #endif
