@@ -22,6 +22,9 @@ typedef half_t R;
 #ifndef RT_H16_LONG_PER_WAVE
 #define RT_H16_LONG_PER_WAVE 16        // pre-classified long chains per thin wave (k_render_h)
 #endif
+#ifndef RT_H16_LONG_RATE
+#define RT_H16_LONG_RATE 14            // a pixel averaging this many bounces per sample (looked at every 4 samples) is a long chain: its wave goes thin; 0 = off
+#endif
 #ifndef RT_H16_PILOT_CAP
 #define RT_H16_PILOT_CAP 35            // bounces after which a pilot sample is cut
 #endif
@@ -585,7 +588,9 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
     const unsigned int n_long_raw = A.long_list ? A.queue[2] : 0u;
     const bool use_long = n_long_raw != 0u && (long long)n_long_raw * 64 <= n_slots;
     const unsigned int n_long = use_long ? n_long_raw : 0u;
-    bool is_long = false, long_done = false, thin = false, retired = false;
+    bool is_long = false, long_done = false, thin = false, retired = false, thin_counted = false;
+    unsigned int iters = 0;                       // bounces spent on the current pixel (in-flight detection of long chains)
+    const unsigned int thin_cap = gridDim.x;      // at most a quarter of the waves may go thin for chains found in flight
 
     long long slot = 0;
     int i = 0, j = 0; long long idx = 0;
@@ -663,7 +668,21 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
     unsigned long long tk0 = H16_TICK(); (void)tk0;
 
     while (true) {
-        if (thin && __ballot(live && is_long) == 0ull) { thin = false; __builtin_amdgcn_s_setprio(0); }      // its chains have ended: refill
+#if RT_H16_LONG_RATE
+        if (!thin && __ballot(live && is_long) != 0ull) {
+            // a chain found in flight (below): the wave stops refilling its other lanes, unless too many waves do so already
+            unsigned int prev = 0;
+            if (lane == 0) prev = atomicAdd(A.queue + 1, 1u);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev < thin_cap) { thin = true; thin_counted = true; __builtin_amdgcn_s_setprio(3); }
+            else { if (lane == 0) atomicSub(A.queue + 1, 1u); is_long = false; }
+        }
+#endif
+        if (thin && __ballot(live && is_long) == 0ull) {                                                       // its chains have ended: refill
+            thin = false; __builtin_amdgcn_s_setprio(0);
+            if (thin_counted && lane == 0) atomicSub(A.queue + 1, 1u);
+            thin_counted = false;
+        }
         if (!thin && !live && !retired && ns > 0) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
         if (__ballot(live) == 0ull) break;
         const R a = vdot(r.d, r.d);
@@ -672,6 +691,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
         else closest_list(A.scene, r, a, closest, best);
         if (live) {
             bool done;
+            ++iters;
             if (best >= 0) {
                 const bool cont = scatter(A.scene, best, closest, r, att, s);
                 ++depth;
@@ -682,10 +702,14 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
             }
             if (done) {
                 ++sample; depth = 0; att = {rd(1.0), rd(1.0), rd(1.0)};
-                if (sample < ns) r = primary_ray(cam, i, j, A.max_x, A.max_y, s);
-                else {
+                if (sample < ns) {
+                    r = primary_ray(cam, i, j, A.max_x, A.max_y, s);
+#if RT_H16_LONG_RATE
+                    if (MODE == 0 && (sample & 3) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_H16_LONG_RATE * sample)) is_long = true;
+#endif
+                } else {
                     end_pixel();
-                    live = false; is_long = false;
+                    live = false; is_long = false; iters = 0;
                     if (lane < RT_H16_LONG_PER_WAVE && begin_long_pixel()) { /* the next long chain */ }
                     else if (!thin) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
                 }
