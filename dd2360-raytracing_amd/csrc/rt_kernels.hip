@@ -1842,7 +1842,7 @@ RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (
 // one thread per 2x2 block: the pilot counts of the block and its eight neighbours decide whether its pixels start as long chains.
 // A neighbour outside the frame, or in a tile of another part of a partitioned frame, counts as the block itself.
 __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigned char* __restrict__ pilot, unsigned char* __restrict__ long_flag,
-                                                    unsigned int* __restrict__ long_list) {
+                                                    unsigned int* __restrict__ long_list, int long_sum) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= A.n_local_tiles * 16) return;
     const long long local_tile = g >> 4;
@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
             }
             sum += v;
         }
-    const bool is_long = sum >= RT_PILOT_LONG_SUM;
+    const bool is_long = sum >= long_sum;
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                          // the 2x2 block this pilot pixel stands for
@@ -2054,10 +2054,11 @@ const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
 
 // after a pilot pass (k_tile_cost here, k_tile_cost_h in rt_kernels_fp16.hip) has written the tile costs and, behind the pixel flags,
 // the per-block counts: the long-chain list (if asked for) and the hand-out order of the tiles
-hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
+// (long_sum: the 3x3 pilot sum from which a block's pixels start as long chains; 0 = this translation unit's RT_PILOT_LONG_SUM)
+hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum) {
     if (flags) {
         const unsigned char* pilot = flags + (size_t)A.n_local_tiles * 64;
-        hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, pilot, flags, long_list);
+        hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, pilot, flags, long_list, long_sum > 0 ? long_sum : RT_PILOT_LONG_SUM);
     }
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
     return hipGetLastError();
@@ -2073,7 +2074,7 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     if (tree && render_variant(true, 0, A.tree.acc) == 4 && RT_PILOT_POOL) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
     else if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
     else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
-    return launch_select_and_order(A, cost, order, flags, long_list, st);
+    return launch_select_and_order(A, cost, order, flags, long_list, st, 0);
 }
 
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {

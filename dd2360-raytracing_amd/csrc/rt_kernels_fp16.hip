@@ -25,6 +25,9 @@ typedef half_t R;
 #ifndef RT_H16_LONG_RATE
 #define RT_H16_LONG_RATE 14            // a pixel averaging this many bounces per sample (looked at every 4 samples) is a long chain: its wave goes thin; 0 = off
 #endif
+#ifndef RT_H16_PILOT_LONG_SUM
+#define RT_H16_PILOT_LONG_SUM 150      // 3x3 pilot sum from which a block's pixels start as long chains (fp32: 200; C4: 200: 57.0 ms, 160: 55.4, 140: 55.1, 120: 55.6, 100: 56.1, 250: 59.7)
+#endif
 #ifndef RT_H16_PILOT_CAP
 #define RT_H16_PILOT_CAP 35            // bounces after which a pilot sample is cut
 #endif
@@ -832,7 +835,7 @@ const char* render_kernel_name_h(bool tree, int mode) {
     return tree ? (mode == 0 ? "k_render_h<true,0>" : "k_render_h<true,1>") : (mode == 0 ? "k_render_h<false,0>" : "k_render_h<false,1>");
 }
 
-hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);   // rt_kernels.hip
+hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum);   // rt_kernels.hip
 
 // the scheduling pre-pass of a binary16 render: pilot pass in binary16, then the precision-independent selection and ordering
 hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
@@ -842,7 +845,7 @@ hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsign
     unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
     if (tree) hipLaunchKernelGGL((h16::k_tile_cost_h<true>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
     else hipLaunchKernelGGL((h16::k_tile_cost_h<false>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
-    return launch_select_and_order(A, cost, order, flags, long_list, st);
+    return launch_select_and_order(A, cost, order, flags, long_list, st, RT_H16_PILOT_LONG_SUM);
 }
 
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
