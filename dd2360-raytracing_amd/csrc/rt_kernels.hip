@@ -52,6 +52,9 @@ namespace rt {
 #ifndef RT_LONG_RATE
 #define RT_LONG_RATE 14
 #endif
+#ifndef RT_LONG_RATE_DENSE
+#define RT_LONG_RATE_DENSE 20    // the dense-grid variant is bound by throughput, not by its chains: C5 663 ms (14: 668)
+#endif
 // at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
 #ifndef RT_THIN_CAP_DEN
 #define RT_THIN_CAP_DEN 4
@@ -1508,7 +1511,7 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
 // sphere and the ground, glass) need 10-15x the average.  One iteration of a full wave costs ~40 k cycles, of a wave
 // with a single live lane ~16 k, so the frame cannot end before (longest chain) x (iteration time of ITS wave).
 // Therefore: slots are interleaved over blocks of 64 tiles (the 64 pixels of a tile go to 64 different lanes/waves: long
-// pixels cluster); a lane whose pixel shows >= RT_LONG_RATE bounces per sample (checked every 8 samples) marks it long;
+// pixels cluster); a lane whose pixel shows >= RT_LONG_RATE bounces per sample (checked every RT_LONG_CHECK samples) marks it long;
 // a wave holding a long pixel stops refilling its other lanes ("thin" wave, raised issue priority) until that pixel is
 // finished, then resumes.  A global counter caps the
 // number of thin waves at a quarter of the grid, so a scene made of long pixels only keeps its throughput.
@@ -1721,7 +1724,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                 if (sample < ns) {
                     { const RenderArgs& C = *cold_args(); r = primary_ray(C.scene.cam, i, j, C.max_x, C.max_y, s); }
                     // classify after every 4th sample while enough of the chain is left for it to matter
-                    if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_LONG_RATE * sample)) {
+                    if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns && iters >= (unsigned int)((COOPG == 2 ? RT_LONG_RATE_DENSE : RT_LONG_RATE) * sample)) {
 #ifdef RT_STATS
                         if (!is_long) ++dbg_long;
 #endif
