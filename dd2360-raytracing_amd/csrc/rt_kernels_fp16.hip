@@ -25,6 +25,12 @@ typedef half_t R;
 #ifndef RT_H16_LONG_RATE
 #define RT_H16_LONG_RATE 14            // a pixel averaging this many bounces per sample (looked at every 4 samples) is a long chain: its wave goes thin; 0 = off
 #endif
+#ifndef RT_H16_LONG_CHECK
+#define RT_H16_LONG_CHECK 4
+#endif
+#ifndef RT_H16_THIN_CAP_DEN
+#define RT_H16_THIN_CAP_DEN 4
+#endif
 #ifndef RT_H16_PILOT_LONG_SUM
 #define RT_H16_PILOT_LONG_SUM 150      // 3x3 pilot sum from which a block's pixels start as long chains (fp32: 200; C4: 200: 57.0 ms, 160: 55.4, 140: 55.1, 120: 55.6, 100: 56.1, 250: 59.7)
 #endif
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
     const unsigned int n_long = use_long ? n_long_raw : 0u;
     bool is_long = false, long_done = false, thin = false, retired = false, thin_counted = false;
     unsigned int iters = 0;                       // bounces spent on the current pixel (in-flight detection of long chains)
-    const unsigned int thin_cap = gridDim.x;      // at most a quarter of the waves may go thin for chains found in flight
+    const unsigned int thin_cap = gridDim.x * 4u / RT_H16_THIN_CAP_DEN;      // at most a quarter of the waves may go thin for chains found in flight
 
     long long slot = 0;
     int i = 0, j = 0; long long idx = 0;
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
                 if (sample < ns) {
                     r = primary_ray(cam, i, j, A.max_x, A.max_y, s);
 #if RT_H16_LONG_RATE
-                    if (MODE == 0 && (sample & 3) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_H16_LONG_RATE * sample)) is_long = true;
+                    if (MODE == 0 && (sample & (RT_H16_LONG_CHECK - 1)) == 0 && sample + 8 <= ns && iters >= (unsigned int)(RT_H16_LONG_RATE * sample)) is_long = true;
 #endif
                 } else {
                     end_pixel();
