@@ -186,8 +186,8 @@ int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, co
  * library (the next call's stream waits for the previous render kernel), so calls on one world from several streams are safe
  * but run one after the other; frames that should overlap on one GPU — two partitions of a frame on two streams — take a
  * context each and go through the *_on entry points.  A context first used inside a hipGraph capture must have been
- * prepared before (rt_render_ctx_reserve, or one uncaptured call of the same frame size); timing events are not recorded
- * during a capture. */
+ * prepared before (rt_render_ctx_reserve, or one uncaptured call of the same frame size — in either precision: the binary16
+ * render has a pilot pass and a workspace too); timing events are not recorded during a capture. */
 int rt_render_ctx_create(rt_render_ctx** out);
 int rt_render_ctx_reserve(rt_render_ctx* ctx, int max_x, int max_y, rt_partition part);   /* workspace for frames of this size, now */
 int rt_render_ctx_destroy(rt_render_ctx* ctx);
