@@ -662,6 +662,23 @@ def test_calls_captured_in_a_hip_graph(rt, cuda):
         g.replay(); torch.cuda.synchronize()
         assert torch.equal(fb.view(torch.int32), fb0.view(torch.int32)) and torch.equal(st, st0)
 
+    # USE_FP16: the binary16 render has a pilot pass, a long-chain list and a tile order of its own (16 spp: all of it on)
+    Wh = rt.World(n, nx, ny, precision=rt.FP16)
+    Oh = rt.Octree(Wh, spl)
+    def render_h(fbh, sth):
+        rt.render_init(nx, ny, sth)
+        rt.render(fbh, nx, ny, 16, Wh, sth, Oh)
+    fb0 = rt.alloc_fb(nx, ny, precision=rt.FP16); st0 = rt.alloc_rand_state(nx, ny)
+    render_h(fb0, st0); torch.cuda.synchronize()                     # direct call = the warm-up of this frame size
+    fb = rt.alloc_fb(nx, ny, precision=rt.FP16); st = rt.alloc_rand_state(nx, ny)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        render_h(fb, st)
+    for _ in range(2):
+        fb.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(fb.view(torch.int16), fb0.view(torch.int16)) and torch.equal(st, st0)
+
 
 @pytest.mark.gpu
 def test_c5_geometry_rows_against_the_oracle(rt, cuda):
