@@ -12,6 +12,11 @@ N > 1   BASELINE config 5, STRONG scaling: the fixed 3840x2160 frame at 256 spp,
         librt_amd.so on the render stream) brings the framebuffer to rank 0, which reassembles it — all inside the timed
         region.  torch.distributed (gloo, 127.0.0.1) only carries the RCCL id, the barriers and the max over ranks.
         --scaling weak keeps round 1's weak-scaled C3 frame (N x 960 000 pixels) for comparison.
+        Started WITHOUT a launcher (`python3 bench.py --gpus N`, no WORLD_SIZE in the environment) the script launches its own
+        N ranks: a parent that never touches torch or the GPU starts `python -m torch.distributed.run --nproc-per-node N
+        bench.py ...` as a child process group, relays rank 0's JSON line, and kills the group and exits non-zero when the job
+        exceeds --timeout (a rank lost before the exchange must not leave the root waiting for ever).  Every rank also carries
+        its own watchdog for the launcher-started form.
 
 Prints ONE JSON line on rank 0.  `roofline` is the algorithmic VALU roofline of the render kernel (SURVEY 8d flops / kernel
 time from HIP events on the launch stream), `roofline_issue` the machine's own view from rocprofv3 PMC passes collected in
@@ -25,9 +30,12 @@ import glob
 import json
 import os
 import shutil
+import signal
+import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,6 +53,7 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (= 
 PEAK_UNFUSED_TOPS = 78.6              # the parity mode's own ceiling (no FMA contraction): PEAK_FP32_VECTOR / 2
 PEAK_VALU_ISSUE_G = 888.0             # G wave-instructions/s the chip sustains on an independent v_fma_f32 stream
                                       # (tools/micro/pk_rate.hip, profiles/micro_pk_rate_r1.txt)
+PEAK_VALU_ISSUE_SPEC_G = PEAK_FP32_VECTOR_TFLOPS * 1e3 / 128.0   # the same from the spec sheet: 157.3 TFLOP/s / (64 lanes x 2 flops) = 1228.9 G
 PEAK_HBM_GBS = 8000.0
 
 PMC_PASSES = [
@@ -108,7 +117,7 @@ def parse_pmc_dir(d):
     return {c: acc[c] / max(1, len(disp[c])) for c in acc}
 
 
-def collect_pmc(config, list_reference):
+def collect_pmc(config, list_reference, timeout=240):
     """rocprofv3 --pmc passes over a short run of this same script (child processes, before this process touches the GPU).
     Returns ({counter: per-dispatch average for the render kernel}, note).  Counters come in their own runs, never together
     with tracing; the profiled program stands directly behind `--`."""
@@ -118,6 +127,8 @@ def collect_pmc(config, list_reference):
     out = {}
     tmp = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)                                     # the child is a one-GPU run of its own, whoever started us
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"]
     if list_reference:
         child.append("--list-reference")
@@ -127,7 +138,7 @@ def collect_pmc(config, list_reference):
             d = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc"] + pmc.split() + ["--output-format", "csv", "-d", d, "--"] + child
             try:
-                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
             except subprocess.TimeoutExpired:
                 note = "pmc pass %d timed out" % i
                 break
@@ -140,6 +151,73 @@ def collect_pmc(config, list_reference):
     return out, note
 
 
+def self_launch(n, argv, timeout):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks as a fresh process group (torch.distributed.run, one
+    process per GPU), relay rank 0's JSON line, enforce the timeout.  This parent imports neither torch nor the library and
+    never touches a GPU; it never execs.  Returns the exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["RT_BENCH_SELF_LAUNCHED"] = "1"                           # the ranks' own watchdogs stand back: this parent's timeout comes first
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)      # a process group of its own: killable as one
+    lines = []
+
+    def pump():
+        for raw in p.stdout:
+            lines.append(raw.decode(errors="replace"))
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = p.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d-rank job did not finish within %d s — killing its process group" % (n, timeout), file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)                              # exactly the group started above
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    t.join(timeout=5)
+    found = None
+    for ln in lines:
+        st = ln.strip()
+        if st.startswith("{") and '"metric"' in st:
+            found = st
+        elif st:
+            print(st, file=sys.stderr)
+    if found is not None and rc == 0:
+        print(found, flush=True)
+        return 0
+    if rc == 0:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+def arm_watchdog(seconds, rank):
+    """launcher-started ranks: a rank that is still here after `seconds` leaves with 124 (torch.distributed.run then stops the
+    others) instead of sitting in a collective for ever"""
+    def fire():
+        print("bench.py rank %d: watchdog after %d s — exiting" % (rank, seconds), file=sys.stderr, flush=True)
+        os._exit(124)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,23 +228,41 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline_issue / traffic become null)")
     ap.add_argument("--list-reference", action="store_true", help="octree-off configs: plain list-order scan instead of the candidate grid")
+    ap.add_argument("--timeout", type=int, default=900, help="N>1: seconds after which the job is killed (self-launched: by the parent; every rank also watches itself)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.timeout))      # before torch, before any GPU call
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without a launcher: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
+    watchdog = arm_watchdog(args.timeout + (60 if os.environ.get("RT_BENCH_SELF_LAUNCHED") == "1" else 0), rank) if world > 1 else None
+    if os.environ.get("RT_BENCH_TEST_HANG") == str(rank):          # tests/test_bench_launch.py: a rank that never arrives
+        watchdog.cancel()
+        time.sleep(3600)
     weak = world > 1 and args.scaling == "weak"
     cfg_key = args.config or ("c3" if (world == 1 or weak) else "c5")
     cfg = CONFIGS[cfg_key]
 
-    # counters first, in child processes, while this process has not touched the GPU yet (N = 1 only)
-    pmc, pmc_note = ({}, "skipped")
-    if world == 1 and not args.no_pmc:
-        pmc, pmc_note = collect_pmc(cfg_key, args.list_reference)
-
     import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # single node: the control plane stays on the loopback
+        dist.init_process_group("gloo")                            # (no GPU involved: the ranks meet before any of them touches one)
+
+    # counters first, in child processes, while NO rank of this job has touched a GPU yet.  N = 1: the workload itself.
+    # N > 1 (strong-scaled C5): rank 0 profiles the same frame on one GPU; a rank's share of those instructions over its own
+    # kernel time is its issue rate (the tile split deals the frame's work out evenly: per_rank_render_ms shows how evenly).
+    pmc, pmc_note = ({}, "skipped")
+    if not args.no_pmc and not weak and rank == 0:
+        pmc, pmc_note = collect_pmc(cfg_key, args.list_reference, timeout=240 if world == 1 else 400)
+    if world > 1:
+        dist.barrier()
+
     import rt_amd as rt
 
     if not torch.cuda.is_available():
@@ -182,11 +278,6 @@ def main():
     rc, _ = rt.device_check()
     if rc != 0:
         raise SystemExit("rt_device_check failed: %d" % rc)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # single node: the control plane stays on the loopback
-        dist.init_process_group("gloo")
 
     nx, ny = cfg["nx"], cfg["ny"]
     if weak:                                                       # same aspect, ~world times the pixels
@@ -203,29 +294,46 @@ def main():
     M = None
     if world > 1:
         transport = "rccl"
+        why_not = "RT_BENCH_SAME_GPU=1" if same_gpu else None
         if not same_gpu:
-            # RCCL inside librt_amd.so: rank 0 creates the id, every rank joins.  Should any rank fail to join (no RCCL, no
-            # peer access), ALL ranks fall back to the host-staged gloo exchange below, and the line says so.
-            ids = [None]
-            try:
-                ids = [rt.multi_unique_id() if rank == 0 else None]
-            except rt.RtError as e:
-                print("rank 0: %s" % e, file=sys.stderr, flush=True)
-            dist.broadcast_object_list(ids, src=0)
-            try:
-                M = rt.Multi(rank, world, unique_id=ids[0]) if ids[0] is not None else None
-            except rt.RtError as e:
-                print("rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
-                M = None
-            ok = torch.tensor([1 if M is not None else 0])
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if M is not None:
-                    M.close()
-                M = None
+            # RCCL inside librt_amd.so.  ncclCommInitRank is collective: a rank that cannot get there (no RCCL, no context, a
+            # device shared with another rank — RCCL refuses two ranks on one device) must be known BEFORE any rank enters it,
+            # or the others wait inside it for ever.  So: every rank probes locally (rt_multi_probe, no communication) and says
+            # which device it sits on; the answers are agreed over gloo; then ALL ranks join the communicator — or none does
+            # and the job takes the host-staged gloo exchange below, and the line says so.
+            mine = [rt.multi_probe(), local_rank, os.environ.get("HIP_VISIBLE_DEVICES", "") + "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "")]
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            devices = [(e[2], e[1]) for e in everyone]
+            if any(e[0] != 0 for e in everyone):
+                why_not = "rt_multi_probe failed on rank(s) %s" % [r for r, e in enumerate(everyone) if e[0] != 0]
+            elif len(set(devices)) < world:
+                why_not = "%d ranks on %d device(s)" % (world, len(set(devices)))
+            if why_not is None:
+                ids = [None]
+                try:
+                    ids = [rt.multi_unique_id() if rank == 0 else None]
+                except rt.RtError as e:
+                    print("rank 0: %s" % e, file=sys.stderr, flush=True)
+                dist.broadcast_object_list(ids, src=0)
+                if ids[0] is None:
+                    why_not = "rt_multi_unique_id failed on rank 0"
+            if why_not is None:
+                try:
+                    M = rt.Multi(rank, world, unique_id=ids[0])      # collective; the watchdog bounds it
+                except rt.RtError as e:
+                    print("rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+                    M = None
+                ok = torch.tensor([1 if M is not None else 0])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if M is not None:
+                        M.close()
+                    M = None
+                    why_not = "ncclCommInitRank failed on a rank"
         if M is None:
             from multi_worker import make_gloo_gather
-            transport = "gloo (host-staged)" + ("" if same_gpu else " — RCCL was not available on every rank")
+            transport = "gloo (host-staged) — %s" % why_not
             M = rt.Multi(rank, world, gather=make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if cfg.get("fp16") else 12))
         M.reserve(nx, ny, precision, 0)
         full = torch.zeros(nx * ny * 3, dtype=torch.float16 if cfg.get("fp16") else torch.float32, device="cuda") if rank == 0 else None
@@ -304,6 +412,8 @@ def main():
         flops_launch = cfg["flops_per_sample"] * local_samples
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+        if world > 1 and fetch_kb is not None and write_kb is not None:      # counters of the one-GPU frame: this rank's share of them
+            fetch_kb, write_kb = fetch_kb * local_samples / float(samples_step), write_kb * local_samples / float(samples_step)
         traffic = int((fetch_kb + write_kb) * 1024) if fetch_kb is not None and write_kb is not None else None
         workload = "%s: %dx%d, %d spp, NUM_SPHERES=%d, USE_OCTREE %s, SPHERES_PER_LEAF=%d, %s, create_world seed 1984" % (
             cfg["name"], nx, ny, spp, cfg["spheres"], "on" if cfg["octree"] else "off", cfg["spl"], "USE_FP16" if cfg.get("fp16") else "fp32")
@@ -332,21 +442,29 @@ def main():
         }
         vi, tc = pmc.get("SQ_INSTS_VALU"), pmc.get("SQ_THREAD_CYCLES_VALU")
         if vi:
-            rate = vi / (kernel_ms * 1e-3) / 1e9
+            share = local_samples / float(samples_step)           # N > 1: this rank's part of the profiled one-GPU frame
+            rate = vi * share / (kernel_ms * 1e-3) / 1e9
             wc = pmc.get("SQ_WAVE_CYCLES")
             out["roofline_issue"] = {
                 "bound": "valu_issue", "kernel": kernel_name, "achieved": round(rate, 2), "peak": PEAK_VALU_ISSUE_G, "unit": "G wave-instructions/s",
                 "frac": round(rate / PEAK_VALU_ISSUE_G, 4),
-                "valu_wave_insts_per_launch": int(vi),
+                "peak_spec": round(PEAK_VALU_ISSUE_SPEC_G, 1), "frac_of_spec": round(rate / PEAK_VALU_ISSUE_SPEC_G, 4),
+                "valu_wave_insts_per_launch": int(vi * share),
                 "lane_utilisation": round(tc / (vi * 64.0), 4) if tc else None,
                 "salu_to_valu": round(pmc["SQ_INSTS_SALU"] / vi, 4) if pmc.get("SQ_INSTS_SALU") else None,
                 "wait_any_share": round(pmc["SQ_WAIT_ANY"] / wc, 4) if pmc.get("SQ_WAIT_ANY") and wc else None,
                 "wait_inst_share": round(pmc["SQ_WAIT_INST_ANY"] / wc, 4) if pmc.get("SQ_WAIT_INST_ANY") and wc else None,
                 "note": "rocprofv3 --pmc passes over 3 launches of this workload in child processes of this run (per-launch averages of the "
-                        "render kernel); SQ_INSTS_VALU / kernel_ms against the issue rate an independent v_fma_f32 stream sustains; "
+                        "render kernel); SQ_INSTS_VALU / kernel_ms.  `peak` is the issue rate an independent v_fma_f32 stream was MEASURED to sustain "
+                        "on this chip (tools/micro/pk_rate.hip), `peak_spec` the spec sheet's 157.3 TFLOP/s / 128 flops per wave-instruction; "
                         "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)" + ("; " + pmc_note if pmc_note else "")}
+            if world > 1:
+                out["roofline_issue"]["note"] += ("; N > 1: the counters are those of the SAME frame rendered on one GPU (rank 0, before the job touched "
+                                                  "a GPU), a rank's instructions = its share of the frame's pixels (%.4f) of them, over its own kernel time" % share)
+                out["roofline_issue"]["per_rank_achieved"] = [round(vi * (rt.part_pixels(nx, ny, rt.Partition(r, world)) * spp / float(samples_step)) / (per_rank[r][1] * 1e-3) / 1e9, 2)
+                                                              for r in range(world)]
         else:
-            out["roofline_issue"] = None if world > 1 else {"note": "no counters: " + str(pmc_note)}
+            out["roofline_issue"] = {"note": "no counters: " + str(pmc_note)}
         # the same kernel against the HBM roof (for the record: it is nowhere near it): algorithmic bytes = RNG state in + out
         # (2 x 48 B) and the vec3 written (12 B) per pixel this rank renders
         alg_bytes = (96.0 + (6.0 if cfg.get("fp16") else 12.0)) * (local_samples / spp)
@@ -362,12 +480,15 @@ def main():
         out["roofline_hbm"]["traffic_fetch_doubled"] = int((2 * fetch_kb + write_kb) * 1024) if traffic is not None else None
         if traffic is None:
             out["roofline_hbm"]["note"] = "96 B curandState in+out + vec3 out (12 B, fp16: 6 B) per pixel / kernel time; no counter passes in this run (%s)" % (
-                "N > 1: the PMC passes belong to the one-GPU run" if world > 1 else pmc_note)
+                pmc_note)
         if per_rank is not None:
-            out["per_rank_render_ms"] = {"call": [p[0] for p in per_rank], "kernel": [p[1] for p in per_rank],
+            ks = [p[1] for p in per_rank]
+            out["per_rank_render_ms"] = {"call": [p[0] for p in per_rank], "kernel": ks,
+                                         "imbalance_max_over_mean": round(max(ks) / (sum(ks) / len(ks)), 4) if min(ks) > 0 else None,
                                          "note": "device time of each rank's own render_init + render (call) and render kernel, mean over the timed steps"}
         if single is not None:
             out["single_gpu_same_frame"] = single
+            out["speedup_vs_single_gpu_same_frame"] = round(single["ms_per_step"] / (dt / args.steps * 1e3), 4)
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             # hitable_list is O(N) per ray: the sample is cut so that it stays ~10 s of wall time on any core count
@@ -390,6 +511,8 @@ def main():
                 out["cpu_baseline_hitTree"] = {"value": round(v2, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
                                                "sample": "%d rows x %d px x %d spp (%d samples), oracle hitTree path, %.1f s wall" % (trows, cfg["nx"], tspp, smp2, secs2)}
         print(json.dumps(out), flush=True)
+    if watchdog is not None:
+        watchdog.cancel()
     if M is not None:
         fence()
         M.close()

@@ -2039,18 +2039,20 @@ hipError_t launch_trace_list(const RenderArgs& A, unsigned blocks, const float* 
 
 #ifndef RT_TU_LIST
 // Which k_render instantiation a call launches — the ONE place that decides (launch_render and rt_render_kernel_name):
-// 0 = k_render<false,MODE,1> (list scan), 1 = k_render<true,MODE,1> (plain), 4 = k_render<true,0,4> (sparse grids: the
-// variant whose cooperative walk serves up to four rays side by side, rt_accel.h: coop_groups)
+// 0 = k_render<false,MODE,1> (list scan), 1 = k_render<true,MODE,1> (per-lane walk: trees without a candidate grid, reference
+// traversal), 4 = k_render<true,MODE,4> (sparse grids: walk_pool), 2 = k_render<true,MODE,2> (dense grids: walk_pool_dense) —
+// render (MODE 0) and render_progressive (MODE 1) walk the same way (rt_accel.h: coop_groups)
 static int render_variant(bool tree, int mode, const DevAccel& acc) {
+    (void)mode;
     if (!tree) return 0;
-    if (mode == 0 && acc.enabled) return acc.coop_groups >= 4 ? 4 : (RT_DENSE_POOL ? 2 : 1);
+    if (acc.enabled) return acc.coop_groups >= 4 ? 4 : (RT_DENSE_POOL ? 2 : 1);
     return 1;
 }
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
     switch (render_variant(tree, mode, acc)) {
         case 0: return mode == 0 ? "k_render<false,0,1>" : "k_render<false,1,1>";
-        case 4: return "k_render<true,0,4>";
-        case 2: return "k_render<true,0,2>";
+        case 4: return mode == 0 ? "k_render<true,0,4>" : "k_render<true,1,4>";
+        case 2: return mode == 0 ? "k_render<true,0,2>" : "k_render<true,1,2>";
         default: return mode == 0 ? "k_render<true,0,1>" : "k_render<true,1,1>";
     }
 }
@@ -2080,20 +2082,28 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     return launch_select_and_order(A, cost, order, flags, long_list, st, 0);
 }
 
+template <int MODE, int COOPG>
+static hipError_t launch_render_tree(const RenderArgs& A, size_t lds, hipStream_t st) {
+    const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
+    // the occupancy query costs as much host time as the launch: remembered per thread for the last (device, LDS size) —
+    // a progressive loop issues the same launch hundreds of times
+    thread_local int c_dev = -1; thread_local size_t c_lds = 0; thread_local unsigned c_cap = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -2;
+    if (dev != c_dev || lds != c_lds || c_cap == 0) { c_cap = resident_blocks(k_render<true, MODE, COOPG>, lds); c_dev = dev; c_lds = lds; }
+    const unsigned cap = c_cap;
+    hipLaunchKernelGGL((k_render<true, MODE, COOPG>), dim3(need < cap ? need : cap), dim3(256), lds, st, A);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const int variant = render_variant(tree, mode, A.tree.acc);
     if (variant == 0) return launch_render_list(A, mode, st);
-    const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
     const size_t lds = tree_lds_bytes(A.tree.n_nodes, variant == 4 || variant == 2);      // (the variants with a pooled walk)
-    const unsigned cap = variant == 4 ? resident_blocks(k_render<true, 0, 4>, lds) : variant == 2 ? resident_blocks(k_render<true, 0, 2>, lds)
-                       : mode == 0 ? resident_blocks(k_render<true, 0, 1>, lds) : resident_blocks(k_render<true, 1, 1>, lds);
-    const unsigned blocks = need < cap ? need : cap;
-    if (variant == 4) hipLaunchKernelGGL((k_render<true, 0, 4>), dim3(blocks), dim3(256), lds, st, A);
-    else if (variant == 2) hipLaunchKernelGGL((k_render<true, 0, 2>), dim3(blocks), dim3(256), lds, st, A);
-    else if (mode == 0) hipLaunchKernelGGL((k_render<true, 0, 1>), dim3(blocks), dim3(256), lds, st, A);
-    else hipLaunchKernelGGL((k_render<true, 1, 1>), dim3(blocks), dim3(256), lds, st, A);
-    return hipGetLastError();
+    if (variant == 4) return mode == 0 ? launch_render_tree<0, 4>(A, lds, st) : launch_render_tree<1, 4>(A, lds, st);
+    if (variant == 2) return mode == 0 ? launch_render_tree<0, 2>(A, lds, st) : launch_render_tree<1, 2>(A, lds, st);
+    return mode == 0 ? launch_render_tree<0, 1>(A, lds, st) : launch_render_tree<1, 1>(A, lds, st);
 }
 
 hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st) {

@@ -16,7 +16,9 @@
 #include <dlfcn.h>
 #include <new>
 #include <cstring>
+#include <mutex>
 #include "../../include/rt_amd.h"
+#include "rt_handles.h"
 
 namespace {
 
@@ -35,12 +37,10 @@ struct Rccl {
     int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     bool ok = false;
 };
-Rccl& rccl() {
-    static Rccl R;
-    if (R.lib) return R;
+void rccl_bind(Rccl& R) {
     R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!R.lib) return R;
+    if (!R.lib) return;
     R.GetUniqueId = (int (*)(NcclId*))dlsym(R.lib, "ncclGetUniqueId");
     R.CommInitRank = (int (*)(NcclComm*, int, NcclId, int))dlsym(R.lib, "ncclCommInitRank");
     R.CommDestroy = (int (*)(NcclComm))dlsym(R.lib, "ncclCommDestroy");
@@ -49,6 +49,11 @@ Rccl& rccl() {
     R.Send = (int (*)(const void*, size_t, int, int, NcclComm, hipStream_t))dlsym(R.lib, "ncclSend");
     R.Recv = (int (*)(void*, size_t, int, int, NcclComm, hipStream_t))dlsym(R.lib, "ncclRecv");
     R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv;
+}
+Rccl& rccl() {                                        // bound once per process, whichever thread asks first
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, rccl_bind, R);
     return R;
 }
 #define RT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -101,6 +106,18 @@ int rt_multi_unique_id(void* id_out) {
     return 0;
 }
 
+// What rt_multi_init needs BEFORE it enters the collective ncclCommInitRank, checked without talking to anybody: RCCL bound
+// with every entry point, and a context + events on the calling process's current device.  A job calls this on every rank,
+// agrees on the answers over its own control plane (gloo, MPI) and only then lets ALL ranks — or none — call rt_multi_init:
+// a rank that returned early from rt_multi_init would leave the others blocked inside the collective.
+int rt_multi_probe(void) {
+    if (!rccl().ok) return RT_ENOTSUP;
+    rt_multi* M = nullptr;
+    const int rc = multi_new(&M, 0, 1);
+    if (rc) return rc;
+    return rt_multi_destroy(M);
+}
+
 int rt_multi_init(rt_multi** out, int rank, int nranks, const void* unique_id) {
     if (!unique_id) return RT_EINVAL;
     Rccl& R = rccl();
@@ -151,6 +168,9 @@ int rt_multi_reserve(rt_multi* M, int max_x, int max_y, int precision, int root)
 int rt_multi_render(rt_multi* M, void* fb_full, int max_x, int max_y, int ns, const rt_world* world, const rt_octree* d_octree, int precision, int root, void* stream) {
     if (!M || !world || max_x <= 0 || max_y <= 0 || ns <= 0 || root < 0 || root >= M->nranks) return RT_EINVAL;
     if (M->rank == root && !fb_full) return RT_EINVAL;
+    // the buffers, the RCCL datatype and rt_assemble are sized by `precision`, the render kernel by the world's: they must agree
+    // (an fp32 world rendered into binary16-sized buffers would write out of bounds)
+    if (precision != world->precision) return RT_EINVAL;
     int rc = rt_multi_reserve(M, max_x, max_y, precision, root);
     if (rc) return rc;
     const hipStream_t st = (hipStream_t)stream;

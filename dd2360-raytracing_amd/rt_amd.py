@@ -80,6 +80,7 @@ SYMBOLS = {
     "rt_render_kernel_name": (_i, [_vp, _vp, _i, _vp, _i]),
     "rt_multi_unique_id": (_i, [_vp]),
     "rt_multi_init": (_i, [_vp, _i, _i, _vp]),
+    "rt_multi_probe": (_i, []),
     "rt_multi_init_custom": (_i, [_vp, _i, _i, _vp, _vp]),
     "rt_multi_destroy": (_i, [_vp]),
     "rt_multi_reserve": (_i, [_vp, _i, _i, _i, _i]),
@@ -201,6 +202,11 @@ def multi_unique_id():
     return buf.raw
 
 
+def multi_probe():
+    """rt_multi_probe: 0 when this rank could enter rt_multi_init's collective part (RCCL bound, context on the current device)"""
+    return int(lib().rt_multi_probe())
+
+
 class Multi:
     """rt_multi: tile split over the ranks of a node + the single framebuffer exchange + rt_assemble on the root.
     unique_id (bytes) selects RCCL; gather (a Python callable with the rt_gather_fn arguments) a custom exchange."""
@@ -220,9 +226,10 @@ class Multi:
         check(lib().rt_multi_reserve(self.h, max_x, max_y, precision, root), "rt_multi_reserve")
         return self
 
-    def render(self, fb_full, max_x, max_y, ns, world, octree=None, root=0):
+    def render(self, fb_full, max_x, max_y, ns, world, octree=None, root=0, precision=None):
         check(lib().rt_multi_render(self.h, _dev(fb_full) if fb_full is not None else None, max_x, max_y, ns, world.h,
-                                    octree.h if octree is not None else None, world.precision, root, _stream()), "rt_multi_render")
+                                    octree.h if octree is not None else None, world.precision if precision is None else precision,
+                                    root, _stream()), "rt_multi_render")
 
     def last_render_ms(self):
         a, b = C.c_float(0), C.c_float(0)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define RT_EINVAL (-1)
@@ -209,8 +209,11 @@ int rt_world_render_times(rt_world* world, float* ms_out, int max, int* count);
 
 /* Scheduling counters of the most recent rt_render on this world / context, read once that launch has finished (waits for it):
  * out4[0] = pixel slots handed out by the work queue, [1] = waves still counted thin (0 after a complete frame), [2] = pixels the
- * pilot pass pre-classified as long chains (0 below 16 samples per pixel or on the binary16 path), [3] = long-chain handles
- * taken.  Diagnostics only — no counterpart in the reference; which lane renders a pixel never changes the pixel. */
+ * pilot pass pre-classified as long chains (0 below 16 samples per pixel; both precisions run the pilot pass), [3] = long-chain
+ * handles taken.  Diagnostics only — no counterpart in the reference; which lane renders a pixel never changes the pixel.
+ * A render captured into a hipGraph pins ONE slot of the context's counter ring and carries no ordering event: while such a graph
+ * replays, its context must not be used by any other launch or replay (they would share the counters, the tile order and the flags) —
+ * give every captured render a context of its own (rt_render_ctx_create). */
 int rt_world_render_counters(rt_world* world, uint32_t* out4);
 int rt_render_ctx_counters(rt_render_ctx* ctx, uint32_t* out4);
 
@@ -229,6 +232,11 @@ int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int n
 #define RT_MULTI_ID_BYTES 128
 int rt_multi_unique_id(void* id_out /* [RT_MULTI_ID_BYTES] */);
 int rt_multi_init(rt_multi** out, int rank, int nranks, const void* unique_id);
+/* Non-collective check of everything rt_multi_init needs before it enters ncclCommInitRank (RCCL bound with all entry points,
+ * a render context and events on the current device): 0, RT_ENOTSUP, or the HIP error.  ncclCommInitRank is collective — a
+ * rank that fails early in rt_multi_init leaves its peers blocked inside it — so a job probes on every rank, agrees on the
+ * result over its own control plane, and then calls rt_multi_init on all ranks or on none (bench.py does). */
+int rt_multi_probe(void);
 /* The same with a caller-supplied exchange (MPI, gloo, a test harness) instead of RCCL.  Called on every rank after its part
  * is rendered (enqueued on `stream`): rank r's send_bytes at d_send must arrive at d_parts + r * part_stride_bytes on the
  * root before work enqueued on the root's stream afterwards runs.  The root's own part is in place already (its d_send IS its
@@ -239,7 +247,8 @@ int rt_multi_destroy(rt_multi* m);
 /* buffers for frames of this size now (otherwise the first rt_multi_render of a larger frame allocates) */
 int rt_multi_reserve(rt_multi* m, int max_x, int max_y, int precision, int root);
 /* render_init + render of this rank's tiles, the exchange, and on the root the assembled frame in fb_full (device buffer of
- * max_x*max_y vec3, reference layout; ignored on the other ranks).  precision must be the world's.  Asynchronous on `stream`. */
+ * max_x*max_y vec3, reference layout; ignored on the other ranks).  precision must be the world's (RT_EINVAL otherwise: it sizes
+ * the part buffers and the exchange).  Asynchronous on `stream`. */
 int rt_multi_render(rt_multi* m, void* fb_full, int max_x, int max_y, int ns, const rt_world* world, const rt_octree* d_octree,
                     int precision, int root, void* stream);
 /* device time of this rank's own share of the last rt_multi_render: render_init + render (call_ms) and the render kernel

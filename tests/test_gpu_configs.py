@@ -158,3 +158,43 @@ def test_image_writers_from_a_device_frame(rt, cuda, tmp_path):
     ref16, _ = OracleScene(n, nx, ny, fp16=True, use_octree=True, spl=spl).render(ns, nthreads=8)
     rt.write_image(p3, host16, nx, ny, precision=rt.FP16, fmt=rt.IMAGE_P3)
     assert p3.read_bytes() == ppm_bytes(ref16)
+
+
+def test_c3_full_size_progressive_64_passes(rt, cuda):
+    """render_progressive (main.cu:119-142) at the C3 frame: 64 one-sample passes at 1200x800, N = 10000, octree SPL 32, through the
+    kernel the library selects for progressive passes on this tree (the pooled walk, k_render<true,1,4>).  The accumulated frame,
+    normalised and gamma-corrected as the viewer does (main.cu:283-284: /n, sqrt), equals the oracle's render(64) rows bit for bit
+    (col = ((0+c1)+c2)+... in both); the RNG states equal those render(64) leaves; and the same through the reference traversal."""
+    torch = cuda
+    nx, ny, ns, n, spl = 1200, 800, 64, 10000, 32
+    W = rt.World(n, nx, ny).upload()
+    O = rt.Octree(W, spl).upload()
+    assert rt.render_kernel_name(W, O, 1) == "k_render<true,1,4>"
+
+    def progressive():
+        st = rt.alloc_rand_state(nx, ny)
+        fb = rt.alloc_fb(nx, ny)
+        rt.render_init(nx, ny, st)
+        for k in range(1, ns + 1):
+            rt.render_progressive(fb, nx, ny, k, W, st, O)
+        torch.cuda.synchronize()
+        return fb, st
+
+    fb, st = progressive()
+    whole, st_whole = render(rt, torch, W, O, nx, ny, ns)
+    assert torch.equal(st.view(torch.uint8), st_whole.view(torch.uint8))              # RNG continuation over 64 launches = one launch of 64
+    acc = fb.cpu().numpy().reshape(ny, nx, 3)
+    shown = np.sqrt(acc * np.float32(1.0 / 64.0))                                     # exact scale, correctly rounded sqrt
+    assert np.array_equal(bits(shown), bits(whole.cpu().numpy().reshape(ny, nx, 3)))
+    S = OracleScene(n, nx, ny, use_octree=True, spl=spl)
+    rows = (3, 250, 316, 317, 600, 797)
+    ref = oracle_rows(S, ns, rows)
+    st_host = st.cpu().numpy().view(np.uint32).reshape(-1, 12)
+    for r in rows:
+        assert np.array_equal(bits(shown[r]), bits(ref[r][0][0])), "row %d differs" % r
+        assert np.array_equal(st_host[r * nx:(r + 1) * nx, :6], ref[r][1][:, :6]), "RNG states of row %d differ" % r
+    O.set_traversal(rt.TRAVERSAL_REFERENCE)                                           # the literal traverseTree scan, per-lane kernel
+    assert rt.render_kernel_name(W, O, 1) == "k_render<true,1,1>"
+    fb2, st2 = progressive()
+    O.set_traversal(rt.TRAVERSAL_FAST)
+    assert torch.equal(fb.view(torch.int32), fb2.view(torch.int32)) and torch.equal(st.view(torch.uint8), st2.view(torch.uint8))

@@ -75,6 +75,46 @@ def test_multi_render_child_processes_on_one_gpu(rt, cuda, world, nx, ny, ns, n,
     assert "EQUALS" in outs[0][1]
 
 
+def test_multi_render_rejects_a_precision_that_is_not_the_worlds(rt, cuda):
+    """rt_multi_render sizes its buffers and the exchange by `precision`, the kernel is chosen by the world's: a mismatch
+    (an fp32 world into binary16-sized buffers = an out-of-bounds write) is refused before anything is launched."""
+    torch = cuda
+    nx, ny = 64, 40
+    W32 = rt.World(22, nx, ny)
+    W16 = rt.World(22, nx, ny, precision=rt.FP16)
+    M = rt.Multi(0, 1, gather=lambda *a: 0)
+    full = torch.zeros(nx * ny * 3, dtype=torch.float32, device="cuda")
+    for W, wrong in ((W32, rt.FP16), (W16, rt.FP32)):
+        with pytest.raises(rt.RtError):
+            M.render(full, nx, ny, 2, W, None, precision=wrong)
+    M.render(full, nx, ny, 2, W32, None)
+    torch.cuda.synchronize()
+    assert rt.multi_probe() == 0                                 # RCCL bound, context + events on this device: no communication involved
+    M.close()
+
+
+def test_bench_self_launch_two_ranks_one_gpu(cuda):
+    """plain `python3 bench.py --gpus 2` (no launcher, no WORLD_SIZE) starts its own ranks as fresh child processes,
+    runs the strong-scaled C5 frame through rt_multi_render and prints ONE result line — here with both ranks on the box's one GPU
+    (RT_BENCH_SAME_GPU=1: the exchange goes through the custom-gather form over gloo; RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, RT_BENCH_SAME_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0, (p.returncode, p.stderr.decode()[-3000:])
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert "C5: 3840x2160, 256 spp, NUM_SPHERES=100000" in d["config"]["workload"]
+    assert d["single_gpu_same_frame"]["frame_equals_multi_gpu_frame"] is True
+    assert d["speedup_vs_single_gpu_same_frame"] > 0
+    assert len(d["per_rank_render_ms"]["kernel"]) == 2 and d["per_rank_render_ms"]["imbalance_max_over_mean"] >= 1.0
+    assert d["roofline"]["frac"] > 0 and "roofline_issue" in d
+
+
 def test_render_calls_on_two_streams(rt, cuda):
     """two partitions of one frame rendered on two streams.  Through the world's own context the calls are
     ordered by the library; with a context each they overlap.  Both ways every part equals the part rendered alone."""
