@@ -24,6 +24,9 @@ struct rt_render_ctx {
     // scheduling workspace (tile costs, hand-out order, long-chain flags and list), grown on demand
     int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
     unsigned int* last_queue = nullptr;      // the counters of the latest launch (rt_render_ctx_counters)
+    // tile order of a progressive sequence (rt_render_progressive): the pilot pass that the call with current_sample == 1 runs, kept
+    // in buffers of its own and reused by the following passes of the same frame (p_key: world and tree serials, frame size, partition)
+    int* p_cost = nullptr; unsigned int* p_order = nullptr; int64_t p_tiles = 0; bool p_valid = false; uint64_t p_key[5] = {0, 0, 0, 0, 0};
     // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_render_ctx_times
     hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
     // ordering of successive launches that share this context
@@ -31,7 +34,10 @@ struct rt_render_ctx {
 };
 static const unsigned kQueueSlots = 64, kQueueStride = 16;
 
+uint64_t rt_next_serial();                  // handles are numbered: a new handle at a recycled address is not mistaken for the old one
+
 struct rt_world {
+    uint64_t serial = rt_next_serial();
     int precision = RT_PRECISION_FP32;
     int n = 0;
     std::vector<float4> h_hot, h_geom, h_mat;
@@ -50,6 +56,7 @@ struct rt_world {
 };
 
 struct rt_octree {
+    uint64_t serial = rt_next_serial();
     int precision = RT_PRECISION_FP32;
     Octree* host = nullptr;
     std::vector<DevNode> h_nodes; std::vector<float4> h_ent_hot; std::vector<int32_t> h_ent_id;

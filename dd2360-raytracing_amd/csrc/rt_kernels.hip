@@ -110,6 +110,12 @@ namespace rt {
 #ifndef RT_LONG_STRIDE
 #define RT_LONG_STRIDE 1
 #endif
+#ifndef RT_PROG_CHUNKED
+#define RT_PROG_CHUNKED 1       // progressive passes take their pixel slots in chunks per wave (see k_render: take_slot)
+#endif
+#ifndef RT_PROG_OWN
+#define RT_PROG_OWN 64          // ... after a share of its own per wave (C3, ms per pass: 0: 0.645, 64: 0.567, 128: 0.611)
+#endif
 #ifndef RT_LONG_PER_WAVE
 #define RT_LONG_PER_WAVE 16     // (4 with the per-lane walk; the pooled walk serves a thin wave of 16 chains: 2: 20.32 ms, 4: 20.04, 8: 19.84, 16: 19.81, 32: 21.92)
 #endif
@@ -1525,7 +1531,6 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     }
     const int lane = threadIdx.x & 63;
     const long long n_slots = A.n_local_tiles * 64;
-    const long long first_free = 0;                                // every slot is handed out by the work counter
     const int ns = (MODE == 0) ? A.ns : 1;
 
     const long long n_waves = (long long)gridDim.x * 4;
@@ -1554,6 +1559,19 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     unsigned long long pix_t0 = 0;
 #endif
 
+    // The next unclaimed slot.  render: one request to the global work counter per lane and pixel (a pixel is ns samples: requests are
+    // rare, and the fine grain balances the frame's tail).  render_progressive hands out a pixel per lane and BOUNCE or so: 1.2 M
+    // requests per C3 pass, one atomic per wave and iteration on one address — 0.3 ms of a 1.0 ms pass.  There a wave owns its first
+    // kProgOwn slots outright (the counter's values start behind all waves' own slots) and then takes the rest in chunks of 64, at
+    // the one place of the main loop where the wave is convergent (`refill_progressive`).
+    constexpr bool kChunked = (MODE == 1) && RT_PROG_CHUNKED;
+    constexpr long long kProgOwn = RT_PROG_OWN;
+    const long long first_free = (kChunked && kProgOwn > 0 && n_waves * kProgOwn <= n_slots) ? n_waves * kProgOwn : 0;
+    long long pool_next = 0, pool_end = 0;              // wave-uniform: this wave's current chunk [pool_next, pool_end)
+    if (kChunked && first_free > 0) { pool_next = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kProgOwn; pool_end = pool_next + kProgOwn; }
+    auto take_slot = [&]() -> long long {
+        return first_free + (long long)atomicAdd(cold_args()->queue, 1u);
+    };
     // claim `slot` (skipping slots that fall outside the frame in edge tiles) and set the lane up for that pixel
     auto begin_pixel = [&]() {
         live = false;
@@ -1583,7 +1601,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 #endif
                 break;
             }
-            slot = first_free + (long long)atomicAdd(A.queue, 1u);
+            slot = take_slot();
         }
         if (!live) retired = true;
         if (live) {
@@ -1654,7 +1672,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     // start: pre-classified long chains first, RT_LONG_PER_WAVE per wave, in waves that are thin from the beginning
     if (lane < RT_LONG_PER_WAVE) begin_long_pixel();
     if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
-    else { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
+    else if (!kChunked) { slot = take_slot(); begin_pixel(); }
 
     const unsigned int thin_cap = (unsigned int)(n_waves / RT_THIN_CAP_DEN);
     float closest = FLT_MAX; int best = -1;
@@ -1678,8 +1696,25 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         }
         if (RT_MED_RATE > 0 && !thin) { if (__ballot(live && is_med) != 0ull) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if (!thin) {
-            // idle lanes (their pixel ended while the wave was thin) go back to the queue
-            if (!live && !retired) { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
+            // idle lanes (their pixel ended while the wave was thin — or, progressive passes, in the previous iteration) go back to the queue
+            if (kChunked) {
+                const bool need = !live && !retired;
+                const unsigned long long mneed = __ballot(need);
+                if (mneed != 0ull) {
+                    const long long n = (long long)__popcll(mneed);
+                    const long long left = pool_end - pool_next;                 // what the current chunk still holds
+                    const long long rank = (long long)__builtin_amdgcn_mbcnt_hi((unsigned)(mneed >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mneed, 0u));
+                    long long fresh = 0;
+                    if (n > left) {                                               // one more chunk for the wave (lane 0 asks)
+                        unsigned int b = 0;
+                        if (lane == 0) b = atomicAdd(cold_args()->queue, 64u);
+                        fresh = first_free + (long long)__builtin_amdgcn_readfirstlane(b);
+                    }
+                    if (need) slot = rank < left ? pool_next + rank : fresh + (rank - left);
+                    if (n > left) { pool_next = fresh + (n - left); pool_end = fresh + 64; } else pool_next += n;
+                    if (need) begin_pixel();
+                }
+            } else if (!live && !retired) { slot = take_slot(); begin_pixel(); }
         }
         // thin implies a live long pixel; otherwise every lane that is not live has just found the queue empty
         if (__ballot(live) == 0ull) break;
@@ -1740,7 +1775,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                     STAT(st, ST_SWITCHES, 1);
                     live = false; is_long = false; is_med = false;
                     if (lane < RT_LONG_PER_WAVE && begin_long_pixel()) { /* next long chain */ }
-                    else if (!thin) { slot = first_free + (long long)atomicAdd(cold_args()->queue, 1u); begin_pixel(); }
+                    else if (!thin && !kChunked) { slot = take_slot(); begin_pixel(); }      // (progressive passes refill at the top of the loop)
                 }
             }
         }
