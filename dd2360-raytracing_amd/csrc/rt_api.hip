@@ -410,7 +410,7 @@ static int octree_upload(const rt_octree* O) {
             }
             d.count = (int32_t)pairs.size() - d.first;
         }
-        if (pairs.size() >= (size_t)1 << 24) return RT_ENOTSUP;         // entry index + 1 shares a dword with the owner lane in the candidate queue
+        if (pairs.size() >= (size_t)1 << 23) return RT_ENOTSUP;         // a pair index shares a dword with a count and the owner lane in the kernels' segment pools (rt_kernels_fp16.hip)
         // plane table: the distinct box coordinates per axis, and per node its six indices into the concatenated table
         std::vector<float> planes; int np[3] = {0, 0, 0};
         {

@@ -18,6 +18,7 @@
 // Binary16 trees (USE_FP16): the same reference layout in real_t = binary16 arithmetic, then the pair layout and plane table the
 // binary16 kernels read, and no candidate grid.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <cmath>
@@ -414,31 +415,36 @@ static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256)
 template <class K> static int sort_keys(K* in, K* out, size_t n, unsigned begin_bit, unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t st) {
     size_t need = 0;
     RT_TRY(rocprim::radix_sort_keys(nullptr, need, in, out, n, begin_bit, end_bit, st));
-    if (need > temp_bytes) return RT_ENOMEM;
+    if (need > temp_bytes) return RT_ENOTSUP;                        // more scratch than the workspace has: the caller builds on the host
     RT_TRY(rocprim::radix_sort_keys(temp, need, in, out, n, begin_bit, end_bit, st));
     return 0;
 }
 static int excl_scan(int* in, int* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st) {
     size_t need = 0;
     RT_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0, n, rocprim::plus<int>(), st));
-    if (need > temp_bytes) return RT_ENOMEM;
+    if (need > temp_bytes) return RT_ENOTSUP;
     RT_TRY(rocprim::exclusive_scan(temp, need, in, out, 0, n, rocprim::plus<int>(), st));
     return 0;
 }
 static unsigned bits_for(unsigned long long v) { unsigned b = 1; while (b < 64 && (v >> b)) ++b; return b; }
 
-template <class R> static const float (*device_boxes(int* rc))[6] {   // the 585 boxes (float images of real_t), uploaded once per process
-    static float (*d_box)[6] = nullptr;
-    if (!d_box) {
+template <class R> static const float (*device_boxes(int* rc))[6] {   // the 585 boxes (float images of real_t), uploaded once per device
+    static std::mutex mu;
+    static float (*d_box[64])[6] = {};                                 // by HIP device ordinal: a pointer is only good on the device that made it
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) { *rc = e != hipSuccess ? (int)e : RT_ENOTSUP; return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!d_box[dev]) {
         static float h_box[kFullNodes][6];
         full_tree_boxes<R>(h_box);
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, sizeof(h_box));
+        e = hipMalloc(&p, sizeof(h_box));
         if (e == hipSuccess) e = hipMemcpy(p, h_box, sizeof(h_box), hipMemcpyHostToDevice);
         if (e != hipSuccess) { if (p) (void)hipFree(p); *rc = (int)e; return nullptr; }
-        d_box = (float (*)[6])p;
+        d_box[dev] = (float (*)[6])p;
     }
-    return d_box;
+    return d_box[dev];
 }
 
 // Builds into O (a fresh handle whose Lazy block is empty).  geom/kind: the world's device copies.  Returns RT_ENOTSUP when the
@@ -549,6 +555,7 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
         RT_TRY(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
         RT_TRY(hipStreamSynchronize(st));
         RT_TRY(hipGetLastError());
+        if (hc.reg_total >= 2u << 23) return RT_ENOTSUP;               // as the host build: a pair index must fit the kernels' segment words
         O->n_nodes = node_count; O->n_entries = (int)hc.n_entries; O->n_world = n;
         Z.dev.n_nodes = node_count; Z.dev.n_entries = (int)hc.reg_total;
         Z.dev.nodes4 = (const float4*)dnodes; Z.dev.ent_hot = (const float4*)h_pairs; Z.dev.ent_id = h_pid;

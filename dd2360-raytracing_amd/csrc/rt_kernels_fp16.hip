@@ -169,26 +169,25 @@ RT_DEV uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 RT_DEV uint32_t dup16(R r) { return (uint32_t)r.bits | ((uint32_t)r.bits << 16); }
 RT_DEV h2 pk_min(h2 a, h2 b) { return __builtin_elementwise_min(a, b); }       // v_pk_min_f16 (minNum: a NaN operand loses)
 
-#ifndef RT_H16_POOL
-#define RT_H16_POOL 256
+// The wave's pool of bucket ranges ("segments") per round.  The tree's level-3 nodes come in two kinds (C4: 64 bottom cells of 25-128
+// pairs, 56 upper cells holding one large sphere each): BIG segments are concatenated and dealt out in equal spans, kPP pairs per
+// lane and pass; SMALL ones (fewer than kSmallPairs pairs) would break every span they fall into — a pass cannot cross a segment
+// boundary — so they go to a pool of their own and are tested one segment per lane.  (One pool for both: 1 pair per pass was the
+// fastest setting, 80.0 ms against 96.6 with 4, because most segments were tiny; split: 4 pairs per pass on the big ones.)
+#ifndef RT_H16_BIG
+#define RT_H16_BIG 128
 #endif
-constexpr int kPool = RT_H16_POOL;                            // segments per wave and round (a multiple of 64)
+#ifndef RT_H16_SMALL
+#define RT_H16_SMALL 256
+#endif
+constexpr int kBig = RT_H16_BIG;                              // big segments per wave and round (a multiple of 64)
+constexpr int kSmall = RT_H16_SMALL;                          // small segments per wave and round
+constexpr unsigned kSmallPairs = 8u;                          // a node with fewer pairs is a small segment (its count must fit 3 bits)
 constexpr int kCand = 128;                                    // candidate queue of a wave
-// pairs per lane and pass of the test loop.  Measured on C4 (ms per frame): 1: 80.0, 2: 83.8, 3: 88.3, 4: 96.6, 6 (3 waves/SIMD): 103.5,
-// 8: 117.7 — a pass cannot cross a segment boundary, and most segments are tiny (the upper cells of the tree hold one of the three
-// large spheres each), so wider passes mostly repeat pairs; more resident waves (5, 6 per SIMD with spills) change nothing
 #ifndef RT_H16_PP
-#define RT_H16_PP 1
+#define RT_H16_PP 4                                           // pairs per lane and pass of the big segments' test loop
 #endif
 constexpr int kPP = RT_H16_PP;
-// spans a lane steps through side by side (independent loads and arithmetic chains).  C4: 1: 76.0 ms, 2: 75.0, 3: 77.7, 4 (3 waves/SIMD): 78.7
-#ifndef RT_H16_SPANS
-#define RT_H16_SPANS 2
-#endif
-constexpr int kNS = RT_H16_SPANS;
-#ifndef RT_H16_BEHIND
-#define RT_H16_BEHIND 0
-#endif
 #ifndef RT_H16_MINWAVES
 #define RT_H16_MINWAVES 4
 #endif
@@ -208,8 +207,9 @@ __device__ unsigned long long g_h16_cyc[8];
 #endif
 constexpr int kPlaneStride = 30;                              // binary16 slots per lane in the plane table (15 dwords: an odd stride)
 struct WaveLds {
-    uint2 seg[kPool];                    // (first pair | owner lane << 26, pairs)
-    unsigned pref[kPool];                // exclusive prefix of pairs
+    uint2 seg[kBig];                     // big segments: (first pair | owner lane << 26, pairs)
+    unsigned sseg[kSmall];               // small segments: first pair | pairs << 23 | owner lane << 26
+    unsigned pref[kBig];                 // exclusive prefix of the big segments' pairs
     unsigned long long key[64];          // per owner: t bits << 32 | entry index + 1
     union {
         unsigned short tp[64 * kPlaneStride];   // phase 1: per lane, the ray's parameter at every box plane of the tree
@@ -218,16 +218,21 @@ struct WaveLds {
             uint2 cq[kCand];             // candidates: (b | disc << 16 as binary16 bits, entry index + 1 << 6 | owner)
         } p2;
     } u;
-    unsigned count, pad_[3];
+    unsigned count, scount, pad_[2];
 };
 static_assert(sizeof(WaveLds) % 16 == 0, "WaveLds keeps 16-byte alignment");
 
 RT_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-RT_DEV unsigned wave_excl_scan(unsigned v, unsigned& total) {   // exclusive prefix sum over the 64 lanes
-    unsigned x = v;
-    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if ((int)(threadIdx.x & 63) >= off) x += y; }
-    total = __shfl(x, 63);
-    return x - v;
+RT_DEV unsigned wave_excl_scan(unsigned v, unsigned& total) {   // exclusive prefix sum over the 64 lanes: six DPP adds, no LDS
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    total = (unsigned)__builtin_amdgcn_readlane(x, 63);
+    return (unsigned)x - v;
 }
 
 // One queued candidate: the offer of sphere::hit (sphere.h:24-43) for a positive discriminant, merged into its owner's key.
@@ -286,27 +291,25 @@ RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
 }
 
 struct PairRay { h2 ox, oy, oz, dx, dy, dz, a; };
-struct Span { unsigned cur, end, seg_end, base, sg; int owner; bool have; PairRay q; };      // a lane's walk through one span of the pool
+RT_DEV PairRay load_pair_ray(const WaveLds& L, int owner) {
+    const uint4 r0 = L.u.p2.ray[2 * owner], r1 = L.u.p2.ray[2 * owner + 1];
+    PairRay q;
+    q.ox = as_h2(r0.x); q.oy = as_h2(r0.y); q.oz = as_h2(r0.z); q.dx = as_h2(r0.w);
+    q.dy = as_h2(r1.x); q.dz = as_h2(r1.y); q.a = as_h2(r1.z);
+    return q;
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Two spheres against one ray: the discriminants of sphere.h:18-22 in packed binary16; v > 0 marks a candidate.
-RT_DEV void pair_math(const PairRay& q, const uint4 p, h2& b, h2& disc, h2& v) {
+// Two spheres against one ray: the discriminants of sphere.h:18-22 in packed binary16 (17 instructions); disc > 0 marks a candidate.
+// (A branch-free packed filter for spheres surely behind the origin — b > 0 and fl(b b) > fl(1.02 disc) — is exact but costs six
+// packed instructions per pair to drop a fifth of the candidates: measured in round 2, 75.8 against 76.6 ms, not kept.)
+RT_DEV void pair_math(const PairRay& q, const u32x4 p, h2& b, h2& disc) {
     const h2 cx = as_h2(p.x), cy = as_h2(p.y), cz = as_h2(p.z), r2 = as_h2(p.w);
     const h2 ocx = q.ox - cx, ocy = q.oy - cy, ocz = q.oz - cz;
     b = (ocx * q.dx + ocy * q.dy) + ocz * q.dz;
     const h2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
     const h2 bb = b * b;
     disc = bb - q.a * cc;
-#if RT_H16_BEHIND
-    // A sphere with b > 0 and fl(b*b) > fl(1.02 disc) lies behind the origin: b^2 > 1.018 disc, so sqrtf(disc) < 0.991 b,
-    // -b + sqrtf(disc) < 0 and both roots are <= 0 (or NaN): neither passes `> t_min`.  min(disc, eps - min(bb - 1.02 disc, b))
-    // is > 0 exactly when disc > 0 and the sphere is not surely behind (eps = the smallest positive binary16; a NaN anywhere
-    // keeps the sphere).  Exact, but six packed instructions per pair to drop a fifth of the candidates: C4 75.8 ms with, 76.6 without.
-    const h2 k102 = as_h2(0x3c143c14u), eps = as_h2(0x00010001u);
-    const h2 u = pk_min(bb - disc * k102, b);
-    v = pk_min(disc, eps - u);
-#else
-    v = disc;
-#endif
 }
 
 // intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
@@ -326,7 +329,9 @@ RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
 }
 
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, WaveLds& L, const Ray& r, R a, bool live, R& closest, int& best) {
-    const uint4* __restrict__ ent = (const uint4*)T.ent_hot;      // packed pairs (rt_api.hip, octree_upload)
+    // the packed pairs (rt_api.hip, octree_upload) through a buffer descriptor: one offset register and immediate offsets serve the
+    // kPP loads of a pass, and a pass may read past the last pair of the array (such loads return zeros; their results are masked)
+    const __amdgpu_buffer_rsrc_t ent = __builtin_amdgcn_make_buffer_rsrc((void*)T.ent_hot, 0, T.n_entries * 8, 0x00020000);
     if (S.ground_valid) {
         int gb = -1;
         sphere_test(r, a, S.list_hot[0], 0, closest, gb);
@@ -340,7 +345,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     const int np0 = T.h16_np[0], np1 = T.h16_np[1], np2 = T.h16_np[2];
     unsigned short* tp = L.u.tp + lane * kPlaneStride;
     while (true) {
-        if (lane == 0) L.count = 0u;
+        if (lane == 0) { L.count = 0u; L.scount = 0u; }
         L.key[lane] = (unsigned long long)closest.bits << 32;
         if (np0 > 0) {
             // the ray's parameter at every box plane: the quotients intersect_ray_aabb forms, one division per plane
@@ -350,17 +355,21 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = ((rf(pl[np0 + np1 + k]) - r.o.z) / r.d.z).bits;
         }
         wave_sync();
-        // ---- phase 1: walk; every visited non-empty node becomes a segment of the pool (or stalls the lane when it is full)
+        // ---- phase 1: walk; every visited non-empty node becomes a segment of one of the pools (or stalls the lane when that pool is full)
         while (node < n_nodes) {
             const float4 n0 = s_nodes[node * 3 + 0];
             const float4 n1 = s_nodes[node * 3 + 1];
             const float4 n2 = s_nodes[node * 3 + 2];
             if (np0 > 0 ? ray_box_tab(tp, (uint32_t)__float_as_int(n2.z)) : ray_box(r, n0, n1)) {
-                const int cnt = __float_as_int(n2.x);
-                if (cnt > 0) {
+                const unsigned cnt = (unsigned)__float_as_int(n2.x);
+                if (cnt >= kSmallPairs) {
                     const unsigned slot = atomicAdd(&L.count, 1u);
-                    if (slot >= (unsigned)kPool) break;              // pool full: this node again next round
-                    L.seg[slot] = make_uint2((uint32_t)__float_as_int(n1.w) | ((uint32_t)lane << 26), (uint32_t)cnt);
+                    if (slot >= (unsigned)kBig) break;               // pool full: this node again next round
+                    L.seg[slot] = make_uint2((uint32_t)__float_as_int(n1.w) | ((uint32_t)lane << 26), cnt);
+                } else if (cnt > 0u) {
+                    const unsigned slot = atomicAdd(&L.scount, 1u);
+                    if (slot >= (unsigned)kSmall) break;
+                    L.sseg[slot] = (uint32_t)__float_as_int(n1.w) | (cnt << 23) | ((uint32_t)lane << 26);
                 }
                 node = node + 1;
             } else {
@@ -369,101 +378,106 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         }
         wave_sync();
         H16_ADD(0, tph);                                             // walk
-        const unsigned n_seg = min(__builtin_amdgcn_readfirstlane(L.count), (unsigned)kPool);
-        if (n_seg == 0u) break;                                      // (then no lane is stalled either)
+        const unsigned n_seg = min(__builtin_amdgcn_readfirstlane(L.count), (unsigned)kBig);
+        const unsigned n_small = min(__builtin_amdgcn_readfirstlane(L.scount), (unsigned)kSmall);
+        if (n_seg == 0u && n_small == 0u) break;                     // (then no lane is stalled either)
         // this lane's ray for whoever tests its spheres (the plane table's space: the walk is over)
         L.u.p2.ray[2 * lane] = make_uint4(dup16(r.o.x), dup16(r.o.y), dup16(r.o.z), dup16(r.d.x));
         L.u.p2.ray[2 * lane + 1] = make_uint4(dup16(r.d.y), dup16(r.d.z), dup16(a), 0u);
-        // ---- phase 2: exclusive prefix of the segments' pair counts, kPool/64 segments per lane
-        unsigned total = 0u;
-        {
-            unsigned run = 0u;
+        unsigned qn = 0u;                                            // candidates queued (wave-uniform)
+        if (n_seg != 0u) {
+            // ---- phase 2a: exclusive prefix of the big segments' pair counts, kBig/64 segments per lane
+            unsigned total = 0u;
+            {
+                unsigned run = 0u;
 #pragma unroll
-            for (int k = 0; k < kPool / 64; ++k) {
-                const unsigned sidx = (unsigned)(k * 64 + lane);
-                const unsigned c = sidx < n_seg ? L.seg[sidx].y : 0u;       // pairs
-                unsigned tot;
-                const unsigned ex = wave_excl_scan(c, tot);
-                if (sidx < n_seg) L.pref[sidx] = run + ex;
-                run += tot;
+                for (int k = 0; k < kBig / 64; ++k) {
+                    const unsigned sidx = (unsigned)(k * 64 + lane);
+                    const unsigned c = sidx < n_seg ? L.seg[sidx].y : 0u;       // pairs
+                    unsigned tot;
+                    const unsigned ex = wave_excl_scan(c, tot);
+                    if (sidx < n_seg) L.pref[sidx] = run + ex;
+                    run += tot;
+                }
+                total = run;
             }
-            total = run;
-        }
-        wave_sync();
-        // every lane takes kNS spans of the pool's concatenated pairs (span j = pairs [j C, (j+1) C)) and steps through them side by
-        // side: kNS loads in flight per lane and kNS independent chains of packed arithmetic (a dependent v_pk_*_f16 issues every
-        // ~9 cycles, independent ones every ~4.5: tools/micro/pk16_rate.hip) without reading past a segment's end
-        const unsigned C = (total + 64u * kNS - 1u) / (64u * kNS);
-        Span sp[kNS];
-#pragma unroll
-        for (int j = 0; j < kNS; ++j) {
-            Span& S = sp[j];
-            const unsigned begin = min((unsigned)(lane + 64 * j) * C, total);
-            S.end = min(begin + C, total); S.cur = begin; S.seg_end = begin;       // seg_end == cur: the first pass loads segment sg
-            S.base = 0u; S.owner = 0; S.have = false; S.sg = 0u;
-            S.q.ox = S.q.oy = S.q.oz = S.q.dx = S.q.dy = S.q.dz = S.q.a = as_h2(0u);
-            if (begin < S.end) {                                     // last segment starting at or before `begin`
+            wave_sync();
+            // every lane takes an equal span of the pool's concatenated pairs and steps through it kPP pairs a pass: kPP loads in
+            // flight and kPP independent chains of packed arithmetic (a dependent v_pk_*_f16 issues every ~9 cycles, independent
+            // ones every ~4.5: tools/micro/pk16_rate.hip); a pass stays inside one segment (one owner's ray)
+            const unsigned C = (total + 63u) / 64u;
+            const unsigned begin = min((unsigned)lane * C, total), end = min(begin + C, total);
+            unsigned cur = begin, seg_end = begin, base = 0u, sg = 0u;      // seg_end == cur: the first pass loads segment sg
+            int owner = 0;
+            PairRay q; q.ox = q.oy = q.oz = q.dx = q.dy = q.dz = q.a = as_h2(0u);
+            if (begin < end) {                                       // last segment starting at or before `begin`
                 unsigned lo = 0u, hi = n_seg;
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < 7; ++it) {                     // kBig <= 128
                     const unsigned mid = (lo + hi) >> 1;
                     if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; }
                 }
-                S.sg = lo;
+                sg = lo;
             }
-        }
-        H16_ADD(1, tph);                                             // prefix + search
-        unsigned qn = 0u;                                            // candidates queued (wave-uniform)
-        while (true) {
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < kNS; ++j) any = any || sp[j].cur < sp[j].end;
-            if (__ballot(any) == 0ull) break;
-            bool act[kNS]; unsigned ix[kNS][kPP], lim[kNS]; uint4 e[kNS][kPP];
-#pragma unroll
-            for (int j = 0; j < kNS; ++j) {
-                Span& S = sp[j];
-                act[j] = S.cur < S.end;
-                if (act[j] && S.cur >= S.seg_end) {
-                    const uint2 sd = L.seg[S.sg];
-                    const unsigned p0 = L.pref[S.sg];
-                    ++S.sg;
-                    S.seg_end = p0 + sd.y;
-                    S.base = (sd.x & 0x3ffffffu) - p0;              // pair `cur` of the pool is pair base + cur of the tree
-                    const int ow = (int)(sd.x >> 26);
-                    if (ow != S.owner || !S.have) {
-                        S.owner = ow; S.have = true;
-                        const uint4 r0 = L.u.p2.ray[2 * ow], r1 = L.u.p2.ray[2 * ow + 1];
-                        S.q.ox = as_h2(r0.x); S.q.oy = as_h2(r0.y); S.q.oz = as_h2(r0.z); S.q.dx = as_h2(r0.w);
-                        S.q.dy = as_h2(r1.x); S.q.dz = as_h2(r1.y); S.q.a = as_h2(r1.z);
-                    }
+            static_assert(kBig <= 128, "binary search depth");
+            H16_ADD(1, tph);                                         // prefix + search
+            while (true) {
+                const bool act = cur < end;
+                if (__ballot(act) == 0ull) break;
+                if (act && cur >= seg_end) {
+                    const uint2 sd = L.seg[sg];
+                    const unsigned p0 = L.pref[sg];
+                    ++sg;
+                    seg_end = min(p0 + sd.y, end);
+                    base = (sd.x & 0x3ffffffu) - p0;                 // pair `cur` of the pool is pair base + cur of the tree
+                    owner = (int)(sd.x >> 26);
+                    q = load_pair_ray(L, owner);
                 }
-                // kPP pairs per span and pass, every lane in step (a span that has ended repeats pair 0 and holds nothing).  A clamped
-                // index repeats a pair: the same key twice, harmless.
-                lim[j] = act[j] ? min(S.seg_end, S.end) : 1u;        // > cur
-                const unsigned last = act[j] ? S.base + lim[j] - 1u : 0u;
-                const unsigned i0 = act[j] ? S.base + S.cur : 0u;
+                const unsigned nb = act ? min((unsigned)kPP, seg_end - cur) : 0u;
+                const unsigned i0 = act ? base + cur : 0u;
+                const int voff = (int)(i0 * 16u);
+                u32x4 e[kPP];
 #pragma unroll
-                for (int k = 0; k < kPP; ++k) { ix[j][k] = min(i0 + (unsigned)k, last); e[j][k] = ent[ix[j][k]]; }
-            }
-            h2 b[kNS][kPP], d[kNS][kPP], v[kNS][kPP];
-            h2 vm = as_h2(0u);
+                for (int k = 0; k < kPP; ++k) e[k] = __builtin_amdgcn_raw_buffer_load_b128(ent, voff, 16 * k, 0);
+                h2 b[kPP], d[kPP];
+                h2 vm = as_h2(0u);
 #pragma unroll
-            for (int j = 0; j < kNS; ++j)
-#pragma unroll
-                for (int k = 0; k < kPP; ++k) { pair_math(sp[j].q, e[j][k], b[j][k], d[j][k], v[j][k]); if (!act[j]) v[j][k] = as_h2(0u); vm = __builtin_elementwise_max(vm, v[j][k]); }
-            if (__ballot((float)vm.x > 0.0f || (float)vm.y > 0.0f) != 0ull) {
-#pragma unroll
-                for (int j = 0; j < kNS; ++j)
+                for (int k = 0; k < kPP; ++k) {
+                    pair_math(q, e[k], b[k], d[k]);
+                    if ((unsigned)k >= nb) d[k] = as_h2(0u);
+                    vm = __builtin_elementwise_max(vm, d[k]);          // (maxNum: a NaN discriminant loses)
+                }
+                if (__ballot(h2_bits(vm) != 0u) != 0ull) {
 #pragma unroll
                     for (int k = 0; k < kPP; ++k) {
-                        push_candidates(L, (float)v[j][k].x > 0.0f, b[j][k].x, d[j][k].x, ix[j][k] * 2u + 1u, sp[j].owner, qn);
-                        push_candidates(L, (float)v[j][k].y > 0.0f, b[j][k].y, d[j][k].y, ix[j][k] * 2u + 2u, sp[j].owner, qn);
+                        push_candidates(L, d[k].x > (_Float16)0, b[k].x, d[k].x, (i0 + (unsigned)k) * 2u + 1u, owner, qn);
+                        push_candidates(L, d[k].y > (_Float16)0, b[k].y, d[k].y, (i0 + (unsigned)k) * 2u + 2u, owner, qn);
                     }
+                }
+                cur += nb;
+                if (qn >= 64u) drain_candidates(L, lane, qn);
             }
-#pragma unroll
-            for (int j = 0; j < kNS; ++j) if (act[j]) sp[j].cur = min(sp[j].cur + (unsigned)kPP, lim[j]);
-            if (qn >= 64u) drain_candidates(L, lane, qn);
+        }
+        // ---- phase 2b: the small segments, one per lane (their pairs one after the other: mostly one)
+        for (unsigned sb = 0u; sb < n_small; sb += 64u) {
+            const unsigned j = sb + (unsigned)lane;
+            const unsigned w = j < n_small ? L.sseg[j] : 0u;
+            const unsigned first = w & 0x7fffffu, cnt = (w >> 23) & 7u;       // (cnt 0: no segment for this lane)
+            const int owner = (int)(w >> 26);
+            const PairRay q = load_pair_ray(L, owner);
+            for (unsigned k = 0u; __ballot(k < cnt) != 0ull; ++k) {
+                const bool act = k < cnt;
+                const unsigned ix = act ? first + k : 0u;
+                const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(ent, (int)(ix * 16u), 0, 0);
+                h2 b, d;
+                pair_math(q, e, b, d);
+                if (!act) d = as_h2(0u);
+                if (__ballot(h2_bits(__builtin_elementwise_max(as_h2(0u), d)) != 0u) != 0ull) {
+                    push_candidates(L, d.x > (_Float16)0, b.x, d.x, ix * 2u + 1u, owner, qn);
+                    push_candidates(L, d.y > (_Float16)0, b.y, d.y, ix * 2u + 2u, owner, qn);
+                }
+                if (qn >= 64u) drain_candidates(L, lane, qn);
+            }
         }
         drain_candidates(L, lane, qn);
         H16_ADD(2, tph);                                             // tests
