@@ -167,7 +167,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 RT_DEV h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
 RT_DEV uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 RT_DEV uint32_t dup16(R r) { return (uint32_t)r.bits | ((uint32_t)r.bits << 16); }
-RT_DEV h2 pk_min(h2 a, h2 b) { return __builtin_elementwise_min(a, b); }       // v_pk_min_f16 (minNum: a NaN operand loses)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 // The wave's pool of bucket ranges ("segments") per round.  The tree's level-3 nodes come in two kinds (C4: 64 bottom cells of 25-128
 // pairs, 56 upper cells holding one large sphere each): BIG segments are concatenated and dealt out in equal spans, kPP pairs per
@@ -185,7 +185,7 @@ constexpr int kSmall = RT_H16_SMALL;                          // small segments 
 constexpr unsigned kSmallPairs = 8u;                          // a node with fewer pairs is a small segment (its count must fit 3 bits)
 constexpr int kCand = 128;                                    // candidate queue of a wave
 #ifndef RT_H16_PP
-#define RT_H16_PP 4                                           // pairs per lane and pass of the big segments' test loop
+#define RT_H16_PP 4                                           // pairs per lane and pass of the big segments' test loop (at most 4: push_pass)
 #endif
 constexpr int kPP = RT_H16_PP;
 #ifndef RT_H16_MINWAVES
@@ -245,6 +245,7 @@ RT_DEV void candidate_eval(WaveLds& L, const uint2 e) {
     ha.bits = (uint16_t)L.u.p2.ray[2 * owner + 1].z;
     hbest.bits = (uint16_t)(((const unsigned*)&L.key[owner])[1]);
     const float b_f = fl(hb), d_f = fl(hd), A = fl(ha), best_f = fl(hbest);
+    if (!(d_f > 0.0f)) return;                                // sphere.h:23 (the packed positive test of push_pass lets a -0 through)
     const float nb = -b_f;
     // cheap filter, margin >= 2x its own error (half an ulp of binary16 on sqrt: 4.9e-4 s; float roundings ~1e-7)
     const float ra = __builtin_amdgcn_rcpf(A);
@@ -264,20 +265,6 @@ RT_DEV void candidate_eval(WaveLds& L, const uint2 e) {
     atomicMin(&L.key[owner], ((unsigned long long)t.bits << 32) | idx1);
 }
 
-// the lanes with p set append (b, disc) to the wave's queue: slots from a wave-uniform count, no atomics
-RT_DEV void push_candidates(WaveLds& L, bool p, _Float16 b, _Float16 disc, uint32_t idx1, int owner, unsigned& qn) {
-    const unsigned long long m = __ballot(p);
-    if (m != 0ull) {
-        const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (p) {
-            const uint2 e = make_uint2((uint32_t)__builtin_bit_cast(uint16_t, b) | ((uint32_t)__builtin_bit_cast(uint16_t, disc) << 16), (idx1 << 6) | (uint32_t)owner);
-            if (slot < (unsigned)kCand) L.u.p2.cq[slot] = e;
-            else candidate_eval(L, e);                         // queue full (a burst of positives): in place
-        }
-        qn += (unsigned)__popcll(m);
-    }
-}
-
 // all queued candidates, 64 at a time
 RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
     wave_sync();
@@ -288,6 +275,49 @@ RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
     }
     qn = 0u;
     wave_sync();
+}
+
+// The positive discriminants of one pass — NP pairs per lane, i.e. up to 2 NP spheres — go into the wave's candidate queue.  One
+// place for all of them: a packed test marks the positive halves (max(disc, 0) is 0 for a negative or NaN discriminant; min_u16 with
+// 1 turns every other half into a 1), then every lane writes its own records, lowest sphere first.
+// (Before: one ballot + mbcnt block per sphere slot, eight per pass, ~10 vector and ~11 scalar instructions each, and the candidate
+// evaluation inlined in each of them for a full queue.)
+// (the pairs' b and discriminant words come by value — arrays indexed by a lane's own bit position would live in scratch memory)
+template <int NP, int STRIDE>
+RT_DEV void push_pass(WaveLds& L, int lane, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
+                      unsigned pair0, int owner, unsigned& qn) {
+    static_assert(NP >= 1 && NP <= 4, "positions 0-3 (x halves) and 16-19 (y halves) of the mask");
+    const uint32_t dd[4] = {d0, d1, d2, d3};
+    uint32_t acc = 0u;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const uint32_t pos = h2_bits(__builtin_elementwise_max(as_h2(dd[k]), as_h2(0u)));      // v_pk_max_f16: 0 for a negative or NaN half
+        uint32_t one;                                                                          // 1 in every half that is not 0
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(pos), "v"(0x00010001u));               // (written out: the optimiser turns the C form back into compares)
+        acc |= one << k;
+    }
+    // one record per lane and turn, the lanes that still hold a positive taking consecutive slots (ballot + mbcnt): two turns a
+    // pass on average; a turn that does not fit the queue drains it first — no candidate is evaluated in place
+    while (true) {
+        const unsigned long long m = __ballot(acc != 0u);
+        if (m == 0ull) break;
+        const unsigned n = (unsigned)__popcll(m);
+        if (qn + n > (unsigned)kCand) drain_candidates(L, lane, qn);
+        if (acc != 0u) {
+            const int p = __builtin_ctz(acc);
+            acc &= acc - 1u;
+            const int pr = p & 3, hi = p >> 4;                // pair of the pass, half of the pair
+            // pair pr of the pass by two levels of selects (v_cndmask), not a chain of branches
+            const bool p1 = (pr & 1) != 0, p2 = (pr & 2) != 0;
+            const uint32_t b01 = p1 ? b1 : b0, b23 = p1 ? b3 : b2, d01 = p1 ? d1 : d0, d23 = p1 ? d3 : d2;
+            const uint32_t bw = p2 ? b23 : b01, dw = p2 ? d23 : d01;
+            const uint32_t rec = hi ? ((bw >> 16) | (dw & 0xffff0000u)) : ((bw & 0xffffu) | (dw << 16));
+            const uint32_t idx1 = (pair0 + (unsigned)(pr * STRIDE)) * 2u + 1u + (unsigned)hi;       // (this lane's pairs of the pass are STRIDE apart)
+            const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            L.u.p2.cq[slot] = make_uint2(rec, (idx1 << 6) | (uint32_t)owner);
+        }
+        qn += n;
+    }
 }
 
 struct PairRay { h2 ox, oy, oz, dx, dy, dz, a; };
@@ -328,6 +358,24 @@ RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
     return true;
 }
 
+// The tree's nodes in LDS.  With a plane table (h16_np[0] > 0: every tree the library builds) the walk needs four words of a node —
+// skip link, first pair, pairs, the six plane indices — and they are staged as ONE 16-byte record per node (one ds_read_b128 a
+// visit instead of three, 2.5 KB instead of 7.5 KB at C4); a tree without the table keeps the full 48-byte nodes (boxes for ray_box).
+// Returns the calling wave's pool, which follows the nodes.
+RT_DEV WaveLds* stage_tree(const DevTree& T, float4* s_nodes) {
+    const bool compact = T.h16_np[0] > 0;
+    if (compact) {
+        for (int t = threadIdx.x; t < T.n_nodes; t += 256) {
+            const float4 n1 = T.nodes4[t * 3 + 1], n2 = T.nodes4[t * 3 + 2];
+            s_nodes[t] = make_float4(n1.z, n1.w, n2.x, n2.z);
+        }
+    } else {
+        for (int t = threadIdx.x; t < T.n_nodes * 3; t += 256) s_nodes[t] = T.nodes4[t];
+    }
+    __syncthreads();
+    return (WaveLds*)(s_nodes + T.n_nodes * (compact ? 1 : 3)) + (threadIdx.x >> 6);
+}
+
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, WaveLds& L, const Ray& r, R a, bool live, R& closest, int& best) {
     // the packed pairs (rt_api.hip, octree_upload) through a buffer descriptor: one offset register and immediate offsets serve the
     // kPP loads of a pass, and a pass may read past the last pair of the array (such loads return zeros; their results are masked)
@@ -355,25 +403,39 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = ((rf(pl[np0 + np1 + k]) - r.o.z) / r.d.z).bits;
         }
         wave_sync();
+#ifdef RT_H16_DOUBLE_WALK      // diagnostic: the walk's cost = the time this build adds (same visits, nothing pooled)
+        { int nd = node; unsigned sink = 0u;
+          while (nd < n_nodes) {
+              const float4 q4 = s_nodes[nd];
+              if (ray_box_tab(tp, (uint32_t)__float_as_int(q4.w))) { sink += (unsigned)__float_as_int(q4.z); nd = nd + 1; } else nd = __float_as_int(q4.x);
+          }
+          asm volatile("" :: "v"(sink)); }
+#endif
         // ---- phase 1: walk; every visited non-empty node becomes a segment of one of the pools (or stalls the lane when that pool is full)
         while (node < n_nodes) {
-            const float4 n0 = s_nodes[node * 3 + 0];
-            const float4 n1 = s_nodes[node * 3 + 1];
-            const float4 n2 = s_nodes[node * 3 + 2];
-            if (np0 > 0 ? ray_box_tab(tp, (uint32_t)__float_as_int(n2.z)) : ray_box(r, n0, n1)) {
-                const unsigned cnt = (unsigned)__float_as_int(n2.x);
+            bool pass; int skip; uint32_t first; unsigned cnt;
+            if (np0 > 0) {
+                const float4 nd = s_nodes[node];                     // (skip, first pair, pairs, plane indices)
+                pass = ray_box_tab(tp, (uint32_t)__float_as_int(nd.w));
+                skip = __float_as_int(nd.x); first = (uint32_t)__float_as_int(nd.y); cnt = (unsigned)__float_as_int(nd.z);
+            } else {
+                const float4 n0 = s_nodes[node * 3 + 0], n1 = s_nodes[node * 3 + 1], n2 = s_nodes[node * 3 + 2];
+                pass = ray_box(r, n0, n1);
+                skip = __float_as_int(n1.z); first = (uint32_t)__float_as_int(n1.w); cnt = (unsigned)__float_as_int(n2.x);
+            }
+            if (pass) {
                 if (cnt >= kSmallPairs) {
                     const unsigned slot = atomicAdd(&L.count, 1u);
                     if (slot >= (unsigned)kBig) break;               // pool full: this node again next round
-                    L.seg[slot] = make_uint2((uint32_t)__float_as_int(n1.w) | ((uint32_t)lane << 26), cnt);
+                    L.seg[slot] = make_uint2(first | ((uint32_t)lane << 26), cnt);
                 } else if (cnt > 0u) {
                     const unsigned slot = atomicAdd(&L.scount, 1u);
                     if (slot >= (unsigned)kSmall) break;
-                    L.sseg[slot] = (uint32_t)__float_as_int(n1.w) | (cnt << 23) | ((uint32_t)lane << 26);
+                    L.sseg[slot] = first | (cnt << 23) | ((uint32_t)lane << 26);
                 }
                 node = node + 1;
             } else {
-                node = __float_as_int(n1.z);
+                node = skip;
             }
         }
         wave_sync();
@@ -404,7 +466,9 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             wave_sync();
             // every lane takes an equal span of the pool's concatenated pairs and steps through it kPP pairs a pass: kPP loads in
             // flight and kPP independent chains of packed arithmetic (a dependent v_pk_*_f16 issues every ~9 cycles, independent
-            // ones every ~4.5: tools/micro/pk16_rate.hip); a pass stays inside one segment (one owner's ray)
+            // ones every ~4.5: tools/micro/pk16_rate.hip); a pass stays inside one segment (one owner's ray).  (A span per QUAD of
+            // lanes, so that every load of a pass reads 64 contiguous bytes per quad, measured the same: 46.7 against 46.0 ms —
+            // the loop is not bound by the texture addresser — and loses more pair slots at segment ends.)
             const unsigned C = (total + 63u) / 64u;
             const unsigned begin = min((unsigned)lane * C, total), end = min(begin + C, total);
             unsigned cur = begin, seg_end = begin, base = 0u, sg = 0u;      // seg_end == cur: the first pass loads segment sg
@@ -421,6 +485,10 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             }
             static_assert(kBig <= 128, "binary search depth");
             H16_ADD(1, tph);                                         // prefix + search
+#ifdef RT_H16_DOUBLE_TESTS     // diagnostic: the big segments' tests twice (the same keys again: the result does not change)
+            for (int rep = 0; rep < 2; ++rep) {
+            cur = begin; seg_end = begin; { unsigned lo = 0u, hi = n_seg; for (int it = 0; it < 7; ++it) { const unsigned mid = (lo + hi) >> 1; if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; } } sg = begin < end ? lo : 0u; }
+#endif
             while (true) {
                 const bool act = cur < end;
                 if (__ballot(act) == 0ull) break;
@@ -447,16 +515,15 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                     if ((unsigned)k >= nb) d[k] = as_h2(0u);
                     vm = __builtin_elementwise_max(vm, d[k]);          // (maxNum: a NaN discriminant loses)
                 }
-                if (__ballot(h2_bits(vm) != 0u) != 0ull) {
-#pragma unroll
-                    for (int k = 0; k < kPP; ++k) {
-                        push_candidates(L, d[k].x > (_Float16)0, b[k].x, d[k].x, (i0 + (unsigned)k) * 2u + 1u, owner, qn);
-                        push_candidates(L, d[k].y > (_Float16)0, b[k].y, d[k].y, (i0 + (unsigned)k) * 2u + 2u, owner, qn);
-                    }
-                }
+                if (__ballot(h2_bits(vm) != 0u) != 0ull)
+                    push_pass<kPP, 1>(L, lane, h2_bits(b[0]), h2_bits(b[kPP > 1 ? 1 : 0]), h2_bits(b[kPP > 2 ? 2 : 0]), h2_bits(b[kPP > 3 ? 3 : 0]),
+                                      h2_bits(d[0]), h2_bits(d[kPP > 1 ? 1 : 0]), h2_bits(d[kPP > 2 ? 2 : 0]), h2_bits(d[kPP > 3 ? 3 : 0]), i0, owner, qn);
                 cur += nb;
                 if (qn >= 64u) drain_candidates(L, lane, qn);
             }
+#ifdef RT_H16_DOUBLE_TESTS
+            }
+#endif
         }
         // ---- phase 2b: the small segments, one per lane (their pairs one after the other: mostly one)
         for (unsigned sb = 0u; sb < n_small; sb += 64u) {
@@ -472,10 +539,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 h2 b, d;
                 pair_math(q, e, b, d);
                 if (!act) d = as_h2(0u);
-                if (__ballot(h2_bits(__builtin_elementwise_max(as_h2(0u), d)) != 0u) != 0ull) {
-                    push_candidates(L, d.x > (_Float16)0, b.x, d.x, ix * 2u + 1u, owner, qn);
-                    push_candidates(L, d.y > (_Float16)0, b.y, d.y, ix * 2u + 2u, owner, qn);
-                }
+                if (__ballot(h2_bits(__builtin_elementwise_max(as_h2(0u), d)) != 0u) != 0ull) push_pass<1, 1>(L, lane, h2_bits(b), 0u, 0u, 0u, h2_bits(d), 0u, 0u, 0u, ix, owner, qn);
                 if (qn >= 64u) drain_candidates(L, lane, qn);
             }
         }
@@ -595,12 +659,7 @@ RT_DEV V sky(const Ray& r, const V& att) {                 // main.cu:67-72
 template <bool TREE, int MODE>
 __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
-    if (TREE) {
-        const int n4 = A.tree.n_nodes * 3;
-        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
-        __syncthreads();
-    }
-    WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? A.tree.n_nodes * 3 : 0)) + (threadIdx.x >> 6);     // this wave's area (TREE only)
+    WaveLds* wl = TREE ? stage_tree(A.tree, s_nodes) : nullptr;       // this wave's pool (TREE only)
     const int lane = threadIdx.x & 63;
     const long long n_slots = A.n_local_tiles * 64;
     const long long first_free = 0;                                // every slot is handed out by the work counter
@@ -748,12 +807,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
 template <bool TREE>
 __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_tile_cost_h(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ pilot) {
     extern __shared__ float4 s_nodes[];
-    if (TREE) {
-        const int n4 = A.tree.n_nodes * 3;
-        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
-        __syncthreads();
-    }
-    WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? A.tree.n_nodes * 3 : 0)) + (threadIdx.x >> 6);
+    WaveLds* wl = TREE ? stage_tree(A.tree, s_nodes) : nullptr;
     const int lane = threadIdx.x & 63;
     const Cam cam = load_camera(A.scene.cam);
     // a wave covers two tiles: 16 blocks x 2 samples each
@@ -800,12 +854,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_tile_cost_h(RenderArgs
 template <bool TREE>
 __global__ __launch_bounds__(256) void k_trace_h(DevScene S, DevTree T, const float* rays, long long n, rt_hit_record* out) {
     extern __shared__ float4 s_nodes[];
-    if (TREE) {
-        const int n4 = T.n_nodes * 3;
-        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = T.nodes4[t];
-        __syncthreads();
-    }
-    WaveLds* wl = (WaveLds*)(s_nodes + (TREE ? T.n_nodes * 3 : 0)) + (threadIdx.x >> 6);
+    WaveLds* wl = TREE ? stage_tree(T, s_nodes) : nullptr;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = gid < n;
     Ray r; r.o = {ri(0), ri(0), ri(0)}; r.d = {ri(0), ri(1), ri(0)};
@@ -855,13 +904,18 @@ const char* render_kernel_name_h(bool tree, int mode) {
     return tree ? (mode == 0 ? "k_render_h<true,0>" : "k_render_h<true,1>") : (mode == 0 ? "k_render_h<false,0>" : "k_render_h<false,1>");
 }
 
+// LDS of a block of the binary16 tree kernels: the nodes (stage_tree), then one WaveLds per wave
+static size_t h16_lds_bytes(bool tree, const DevTree& T) {
+    return tree ? (size_t)T.n_nodes * (T.h16_np[0] > 0 ? sizeof(float4) : sizeof(DevNode)) + 4 * sizeof(h16::WaveLds) : 0;
+}
+
 hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum);   // rt_kernels.hip
 
 // the scheduling pre-pass of a binary16 render: pilot pass in binary16, then the precision-independent selection and ordering
 hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((A.n_local_tiles + 7) / 8);                 // a wave covers two tiles
-    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) + 4 * sizeof(h16::WaveLds) : 0;
+    const size_t lds = h16_lds_bytes(tree, A.tree);
     unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
     if (tree) hipLaunchKernelGGL((h16::k_tile_cost_h<true>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
     else hipLaunchKernelGGL((h16::k_tile_cost_h<false>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
@@ -871,7 +925,7 @@ hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsign
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
-    const size_t lds = tree ? (size_t)A.tree.n_nodes * sizeof(DevNode) + 4 * sizeof(h16::WaveLds) : 0;
+    const size_t lds = h16_lds_bytes(tree, A.tree);
     void (*k)(RenderArgs) = tree ? (mode == 0 ? h16::k_render_h<true, 0> : h16::k_render_h<true, 1>)
                                  : (mode == 0 ? h16::k_render_h<false, 0> : h16::k_render_h<false, 1>);
     const unsigned cap = resident_blocks_h((const void*)k, lds);
@@ -883,7 +937,7 @@ hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t
 hipError_t launch_trace_h(const DevScene& S, const DevTree& T, bool tree, const float* rays, long long n, rt_hit_record* out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    const size_t lds = tree ? (size_t)T.n_nodes * sizeof(DevNode) + 4 * sizeof(h16::WaveLds) : 0;
+    const size_t lds = h16_lds_bytes(tree, T);
     if (tree) hipLaunchKernelGGL((h16::k_trace_h<true>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
     else hipLaunchKernelGGL((h16::k_trace_h<false>), dim3(blocks), dim3(256), lds, st, S, T, rays, n, out);
     return hipGetLastError();
