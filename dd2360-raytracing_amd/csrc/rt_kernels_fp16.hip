@@ -362,6 +362,7 @@ RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
 // skip link, first pair, pairs, the six plane indices — and they are staged as ONE 16-byte record per node (one ds_read_b128 a
 // visit instead of three, 2.5 KB instead of 7.5 KB at C4); a tree without the table keeps the full 48-byte nodes (boxes for ray_box).
 // Returns the calling wave's pool, which follows the nodes.
+RT_DEV bool regular_planes(const DevTree& T) { return T.h16_np[0] == 9 && T.h16_np[1] == 9 && T.h16_np[2] == 9; }
 RT_DEV WaveLds* stage_tree(const DevTree& T, float4* s_nodes) {
     const bool compact = T.h16_np[0] > 0;
     if (compact) {
@@ -369,11 +370,64 @@ RT_DEV WaveLds* stage_tree(const DevTree& T, float4* s_nodes) {
             const float4 n1 = T.nodes4[t * 3 + 1], n2 = T.nodes4[t * 3 + 2];
             s_nodes[t] = make_float4(n1.z, n1.w, n2.x, n2.z);
         }
+        __syncthreads();
+        // behind the records: per node its eight children by octant (node index as 16 bits, 0 = no such child) — closest_tree expands
+        // a node by testing all its children at once (below).  A child follows its parent in pre-order, its siblings follow at the
+        // skip links; its octant is read off the plane indices: high half on an axis <=> its low plane is not the parent's.
+        if (regular_planes(T)) {
+            uint4* s_child = (uint4*)(s_nodes + T.n_nodes);
+            for (int t = threadIdx.x; t < T.n_nodes; t += 256) {
+                const uint32_t w = (uint32_t)__float_as_int(s_nodes[t].w);
+                uint32_t ch[4] = {0u, 0u, 0u, 0u}, exist = 0u;
+                const bool inner = ((w >> 5) & 31u) - (w & 31u) > 1u;   // its box spans more than one plane step
+                if (inner) {
+                    const int end = __float_as_int(s_nodes[t].x);
+                    for (int c = t + 1; c < end; c = __float_as_int(s_nodes[c].x)) {
+                        const uint32_t wc = (uint32_t)__float_as_int(s_nodes[c].w);
+                        const int oct = ((wc & 31u) != (w & 31u) ? 4 : 0) | (((wc >> 10) & 31u) != ((w >> 10) & 31u) ? 2 : 0) | (((wc >> 20) & 31u) != ((w >> 20) & 31u) ? 1 : 0);
+                        ch[oct >> 1] |= (uint32_t)c << (16 * (oct & 1));
+                        exist |= 1u << oct;
+                    }
+                }
+                s_child[t] = make_uint4(ch[0], ch[1], ch[2], ch[3]);
+                if (inner) s_nodes[t].y = __int_as_float((int)exist);   // (an inner node has no bucket range: the word holds which children exist)
+            }
+        }
     } else {
         for (int t = threadIdx.x; t < T.n_nodes * 3; t += 256) s_nodes[t] = T.nodes4[t];
     }
     __syncthreads();
-    return (WaveLds*)(s_nodes + T.n_nodes * (compact ? 1 : 3)) + (threadIdx.x >> 6);
+    return (WaveLds*)(s_nodes + T.n_nodes * (compact ? (regular_planes(T) ? 2 : 1) : 3)) + (threadIdx.x >> 6);
+}
+
+// intersect_ray_aabb for the EIGHT children of a node at once (regular trees: a child box is a half of the parent's on every axis,
+// cut at the parent's middle plane — nine plane parameters instead of 8 x 6, one LDS round trip).  Every child's test is the function
+// ray_box_tab computes of its six parameters — the same comparisons in the same order, shared where children share a half.
+// Returns the children that pass, bit 4 (x high) + 2 (y high) + (z high) — acceleration_structure.h:149-165.
+RT_DEV unsigned expand_node(const unsigned short* tp, uint32_t w) {
+    auto T = [&](uint32_t i) { R h; h.bits = tp[i]; return fl(h); };
+    const uint32_t i0 = w & 31u, i1 = (w >> 5) & 31u, j0 = (w >> 10) & 31u, j1 = (w >> 15) & 31u, k0 = (w >> 20) & 31u, k1 = (w >> 25) & 31u;
+    const float tx0 = T(i0), txm = T((i0 + i1) >> 1), tx1 = T(i1), ty0 = T(j0), tym = T((j0 + j1) >> 1), ty1 = T(j1), tz0 = T(k0), tzm = T((k0 + k1) >> 1), tz1 = T(k1);
+    float lo[3][2], hi[3][2];                                    // [axis][half]: the slab interval after the reference's swap
+    auto slab = [&](int ax, int h, float a, float b) { if (a > b) { const float t = a; a = b; b = t; } lo[ax][h] = a; hi[ax][h] = b; };
+    slab(0, 0, tx0, txm); slab(0, 1, txm, tx1); slab(1, 0, ty0, tym); slab(1, 1, tym, ty1); slab(2, 0, tz0, tzm); slab(2, 1, tzm, tz1);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+        for (int yh = 0; yh < 2; ++yh) {
+            float tmin = lo[0][xh], tmax = hi[0][xh];
+            const float tymin = lo[1][yh], tymax = hi[1][yh];
+            const bool xy = !((tmin > tymax) || (tymin > tmax));
+            if (tymin > tmin) tmin = tymin;
+            if (tymax < tmax) tmax = tymax;
+#pragma unroll
+            for (int zh = 0; zh < 2; ++zh) {
+                const bool ok = xy && !((tmin > hi[2][zh]) || (lo[2][zh] > tmax));
+                mask |= ok ? 1u << (4 * xh + 2 * yh + zh) : 0u;
+            }
+        }
+    return mask;
 }
 
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, WaveLds& L, const Ray& r, R a, bool live, R& closest, int& best) {
@@ -391,6 +445,12 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     int node = live ? 0 : T.n_nodes;
     const int n_nodes = T.n_nodes;
     const int np0 = T.h16_np[0], np1 = T.h16_np[1], np2 = T.h16_np[2];
+    const bool regular = regular_planes(T);
+    // the walk of a regular tree (below): which level the lane is expanding (-1: done, -2: not started), the level-1 and level-2
+    // nodes it is inside, and per level the children that passed and are still to be visited
+    int lvl = live ? -2 : -1, wn1 = 0, wn2 = 0;
+    unsigned wm0 = 0u, wm1 = 0u, wm2 = 0u;
+    const unsigned short* s_child16 = (const unsigned short*)(s_nodes + n_nodes);
     unsigned short* tp = L.u.tp + lane * kPlaneStride;
     while (true) {
         if (lane == 0) { L.count = 0u; L.scount = 0u; }
@@ -403,15 +463,53 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = ((rf(pl[np0 + np1 + k]) - r.o.z) / r.d.z).bits;
         }
         wave_sync();
-#ifdef RT_H16_DOUBLE_WALK      // diagnostic: the walk's cost = the time this build adds (same visits, nothing pooled)
-        { int nd = node; unsigned sink = 0u;
-          while (nd < n_nodes) {
-              const float4 q4 = s_nodes[nd];
-              if (ray_box_tab(tp, (uint32_t)__float_as_int(q4.w))) { sink += (unsigned)__float_as_int(q4.z); nd = nd + 1; } else nd = __float_as_int(q4.x);
-          }
-          asm volatile("" :: "v"(sink)); }
-#endif
-        // ---- phase 1: walk; every visited non-empty node becomes a segment of one of the pools (or stalls the lane when that pool is full)
+        // ---- phase 1: walk; every visited non-empty level-3 node becomes a segment of one of the pools (or stalls the lane when that
+        //      pool is full).  traverseTree (acceleration_structure.h:276-304) visits a node's non-zero children in index order,
+        //      each after its own slab test; which nodes are visited does not depend on the order, and neither does the result (above).
+        if (regular) {
+            // A step of the lane is either the expansion of an inner node — its eight children's slab tests at once — or the visit
+            // of a level-3 child that passed: ~11 steps a ray instead of one dependent LDS chain per tested node (27 a ray).
+            if (lvl == -2) {
+                lvl = -1;
+                const uint32_t w0 = (uint32_t)__float_as_int(s_nodes[0].w);
+                if (ray_box_tab(tp, w0)) {
+                    if (((w0 >> 5) & 31u) - (w0 & 31u) > 1u) { wm0 = expand_node(tp, w0) & (unsigned)__float_as_int(s_nodes[0].y); lvl = 0; }
+                }
+            }
+            // (wm2: level-3 children of the level-2 node wn2 that passed and are still to be pooled — visited right after the
+            // expansion that found them, left over only when a pool was full)
+            auto pool_leaves = [&]() -> bool {                          // false: a pool is full, the rest waits for the next round
+                while (wm2 != 0u) {
+                    const int c = __builtin_ctz(wm2);
+                    const float4 nd = s_nodes[(int)s_child16[wn2 * 8 + c]];         // (skip, first pair, pairs, plane indices)
+                    const uint32_t first = (uint32_t)__float_as_int(nd.y); const unsigned cnt = (unsigned)__float_as_int(nd.z);
+                    if (cnt >= kSmallPairs) {
+                        const unsigned slot = atomicAdd(&L.count, 1u);
+                        if (slot >= (unsigned)kBig) return false;
+                        L.seg[slot] = make_uint2(first | ((uint32_t)lane << 26), cnt);
+                    } else if (cnt > 0u) {
+                        const unsigned slot = atomicAdd(&L.scount, 1u);
+                        if (slot >= (unsigned)kSmall) return false;
+                        L.sseg[slot] = first | (cnt << 23) | ((uint32_t)lane << 26);
+                    }
+                    wm2 &= wm2 - 1u;
+                }
+                return true;
+            };
+            bool room = pool_leaves();                                  // (left over from the previous round)
+            while (room && lvl >= 0) {                                  // lvl 0: inside the root, 1: inside the level-1 node wn1
+                const unsigned m = lvl == 0 ? wm0 : wm1;
+                if (m == 0u) { --lvl; continue; }
+                const int c = __builtin_ctz(m);
+                const int child = (int)s_child16[(lvl == 0 ? 0 : wn1) * 8 + c];
+                if (lvl == 0) wm0 = m & (m - 1u); else wm1 = m & (m - 1u);
+                const float4 nd = s_nodes[child];                      // (skip, existing children, -, plane indices)
+                const unsigned cm = expand_node(tp, (uint32_t)__float_as_int(nd.w)) & (unsigned)__float_as_int(nd.y);      // ... of the children that exist
+                if (lvl == 0) { wn1 = child; wm1 = cm; lvl = 1; }
+                else { wn2 = child; wm2 = cm; room = pool_leaves(); }
+            }
+            if (lvl < 0 && wm2 == 0u) node = n_nodes;
+        } else
         while (node < n_nodes) {
             bool pass; int skip; uint32_t first; unsigned cnt;
             if (np0 > 0) {
@@ -906,7 +1004,8 @@ const char* render_kernel_name_h(bool tree, int mode) {
 
 // LDS of a block of the binary16 tree kernels: the nodes (stage_tree), then one WaveLds per wave
 static size_t h16_lds_bytes(bool tree, const DevTree& T) {
-    return tree ? (size_t)T.n_nodes * (T.h16_np[0] > 0 ? sizeof(float4) : sizeof(DevNode)) + 4 * sizeof(h16::WaveLds) : 0;
+    const bool regular = T.h16_np[0] == 9 && T.h16_np[1] == 9 && T.h16_np[2] == 9;
+    return tree ? (size_t)T.n_nodes * (T.h16_np[0] > 0 ? (regular ? 2 : 1) * sizeof(float4) : sizeof(DevNode)) + 4 * sizeof(h16::WaveLds) : 0;
 }
 
 hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum);   // rt_kernels.hip
