@@ -132,6 +132,8 @@ def collect_pmc(config, list_reference, timeout=240):
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"]
     if list_reference:
         child.append("--list-reference")
+    if "--arith" in sys.argv:
+        child += ["--arith", sys.argv[sys.argv.index("--arith") + 1]]
     note = None
     try:
         for i, pmc in enumerate(PMC_PASSES):
@@ -228,6 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline_issue / traffic become null)")
     ap.add_argument("--list-reference", action="store_true", help="octree-off configs: plain list-order scan instead of the candidate grid")
+    ap.add_argument("--arith", default="ieee", choices=["ieee", "contract"], help="contract: the opt-in tolerance mode with FMA contraction allowed (rt_world_set_arith) — never the parity mode, reported separately")
     ap.add_argument("--timeout", type=int, default=900, help="N>1: seconds after which the job is killed (self-launched: by the parent; every rank also watches itself)")
     args = ap.parse_args()
 
@@ -289,6 +292,8 @@ def main():
     W = rt.World(cfg["spheres"], nx, ny, precision=precision).upload()
     if args.list_reference:
         W.set_list_traversal(rt.TRAVERSAL_REFERENCE)
+    if args.arith == "contract":
+        W.set_arith(rt.ARITH_CONTRACT)
     O = rt.Octree(W, cfg["spl"]).upload() if cfg["octree"] else None
     kernel_name = rt.render_kernel_name(W, O, 0)                   # the library's own selection, as rocprofv3 names it
     M = None
@@ -417,6 +422,8 @@ def main():
         traffic = int((fetch_kb + write_kb) * 1024) if fetch_kb is not None and write_kb is not None else None
         workload = "%s: %dx%d, %d spp, NUM_SPHERES=%d, USE_OCTREE %s, SPHERES_PER_LEAF=%d, %s, create_world seed 1984" % (
             cfg["name"], nx, ny, spp, cfg["spheres"], "on" if cfg["octree"] else "off", cfg["spl"], "USE_FP16" if cfg.get("fp16") else "fp32")
+        if args.arith == "contract":
+            workload += "; ARITHMETIC: FMA contraction allowed (RT_ARITH_CONTRACT) - a tolerance mode, NOT the pixel-identical parity mode"
         if world > 1:
             workload += ("; frame grown to %d x 960000 px" % world if weak else "; the fixed frame") + \
                         ", 8x8 tiles round-robin over %d GPUs (rt_multi_render), one exchange to rank 0 over %s" % (world, transport)

@@ -17,6 +17,7 @@ namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
 hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
+namespace fmac { hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st); }      // rt_kernels_contract.hip
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
@@ -200,6 +201,12 @@ int rt_world_set_list_traversal(rt_world* W, int mode) {
     return 0;
 }
 
+int rt_world_set_arith(rt_world* W, int mode) {
+    if (!W || (mode != RT_ARITH_IEEE && mode != RT_ARITH_CONTRACT)) return RT_EINVAL;
+    if (mode == RT_ARITH_CONTRACT && W->precision == RT_PRECISION_FP16) return RT_ENOTSUP;
+    W->arith = mode;
+    return 0;
+}
 int rt_world_list_accel_info(const rt_world* W, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres) {
     if (!W) return RT_EINVAL;
     rt_octree* LT = ensure_list_tree(W);
@@ -746,6 +753,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     const unsigned ek = C.ev_head % 64u;
     if (!cap) RT_TRY(hipEventRecord(C.ev0[ek], st));
     if (world->precision == RT_PRECISION_FP16) RT_TRY(launch_render_h(A, d_octree != nullptr, mode, st));
+    else if (world->arith == RT_ARITH_CONTRACT) RT_TRY(fmac::launch_render(A, d_octree != nullptr, mode, st));
     else RT_TRY(launch_render(A, d_octree != nullptr, mode, st));
     if (!cap) {
         RT_TRY(hipEventRecord(C.ev1[ek], st));

@@ -43,6 +43,7 @@ struct rt_world {
     std::vector<float4> h_hot, h_geom, h_mat;
     std::vector<int32_t> h_ids, h_kind;
     int list_traversal = RT_TRAVERSAL_FAST;
+    int arith = RT_ARITH_IEEE;                 // rt_world_set_arith
     struct Lazy {
         bool uploaded = false;
         DevScene dev{};

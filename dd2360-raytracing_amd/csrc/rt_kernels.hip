@@ -25,9 +25,18 @@
 #include <float.h>
 #include "rt_device.h"
 
+// RT_TU_CONTRACT (rt_kernels_contract.hip): the same source once more with FMA contraction ALLOWED — what nvcc's default -fmad=true
+// does to the reference (Makefile:9) — in a namespace of its own, for rt_world_set_arith(RT_ARITH_CONTRACT).  Never the parity mode.
+#ifdef RT_TU_CONTRACT
+#pragma clang fp contract(fast)
+#else
 #pragma clang fp contract(off)
+#endif
 
 namespace rt {
+#ifdef RT_TU_CONTRACT
+namespace fmac {
+#endif
 
 #define RT_DEV static __device__ __forceinline__
 
@@ -2175,4 +2184,7 @@ hipError_t read_stats(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef RT_TU_CONTRACT
+} // namespace fmac
+#endif
 } // namespace rt

@@ -15,6 +15,7 @@ FP32, FP16 = 0, 1
 MAT_NONE, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = -1, 0, 1, 2
 OCTREE_MAX_NODES = 585
 TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
+ARITH_IEEE, ARITH_CONTRACT = 0, 1
 IMAGE_P3, IMAGE_P6, IMAGE_PFM = 0, 1, 2
 
 # PODs of include/rt_amd.h
@@ -60,6 +61,7 @@ SYMBOLS = {
     "rt_octree_flat_info": (_i, [_vp, _vp, _vp]),
     "rt_octree_set_traversal": (_i, [_vp, _i]),
     "rt_world_set_list_traversal": (_i, [_vp, _i]),
+    "rt_world_set_arith": (_i, [_vp, _i]),
     "rt_world_list_accel_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rt_octree_accel_info": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rt_octree_nodes": (_i, [_vp, _vp]),
@@ -294,6 +296,11 @@ class World:
     def set_list_traversal(self, mode):
         """TRAVERSAL_REFERENCE (every sphere in list order) or TRAVERSAL_FAST (default: the candidate grid) for renders without an octree"""
         check(lib().rt_world_set_list_traversal(self.h, mode), "rt_world_set_list_traversal")
+        return self
+
+    def set_arith(self, mode):
+        """ARITH_IEEE (default, the parity contract) or ARITH_CONTRACT (FMA contraction allowed: a tolerance mode)"""
+        check(lib().rt_world_set_arith(self.h, mode), "rt_world_set_arith")
         return self
 
     def list_accel_info(self):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define RT_EINVAL (-1)
@@ -132,6 +132,16 @@ int rt_world_upload(rt_world* world);
  * FP16 worlds, lists of fewer than 64 spheres and lists with more than 64 spheres outside the grid's range always use
  * REFERENCE.  The grid is built by the first call that needs it (a render/trace without an octree, or the info call). */
 int rt_world_set_list_traversal(rt_world* world, int mode);   /* RT_TRAVERSAL_REFERENCE | RT_TRAVERSAL_FAST */
+/* Arithmetic of the fp32 render kernels on this world.  RT_ARITH_IEEE (default): one IEEE binary32 rounding per operation of the
+ * reference source, no FMA contraction — the parity contract.  RT_ARITH_CONTRACT: the same kernels compiled with
+ * contraction allowed, as nvcc does by default to the reference (Makefile:9 passes no -fmad=false): a*b+c may become one fma with a
+ * single rounding (3 instead of 5 operations a dot product).  Pixels then differ from the parity mode in the last bits, and where a
+ * last bit flips a decision (a rejection-loop test, a grazing hit) in whole samples: a TOLERANCE mode — tests/test_gpu_contract.py
+ * states the measured bounds — reported separately by bench.py --arith contract, never the default.  rt_render / rt_render_progressive
+ * only (rt_trace_rays stays IEEE); RT_ENOTSUP for USE_FP16 worlds (binary16 operations are single instructions either way). */
+#define RT_ARITH_IEEE 0
+#define RT_ARITH_CONTRACT 1
+int rt_world_set_arith(rt_world* world, int mode);
 int rt_world_list_accel_info(const rt_world* world, int* enabled, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres);
 /* free_world<<<1,1>>> + cudaFree — main.cu:206-219, :464-466. */
 int rt_free_world(rt_world* world);

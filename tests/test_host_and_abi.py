@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol(rt):
     L = rt.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 3
+    assert L.rt_abi_version() == 4
 
 
 def test_pod_sizes_match_reference_structs(rt):
