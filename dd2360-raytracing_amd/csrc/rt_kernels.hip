@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "rt_device.h"
+#include "rt_tuning.h"
 
 // RT_TU_CONTRACT (rt_kernels_contract.hip): the same source once more with FMA contraction ALLOWED — what nvcc's default -fmad=true
 // does to the reference (Makefile:9) — in a namespace of its own, for rt_world_set_arith(RT_ARITH_CONTRACT).  Never the parity mode.
@@ -40,136 +41,7 @@ namespace fmac {
 
 #define RT_DEV static __device__ __forceinline__
 
-// minimum waves per SIMD the render kernel is compiled for (register budget 512/RT_RENDER_WAVES VGPRs per lane)
-#ifndef RT_COOP_SPARSE
-#define RT_COOP_SPARSE 0       // cooperative single-ray walks in the pooled variant for waves with <= this many walkers (1, 2: within the run-to-run noise of 0)
-#endif
-#ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 4
-#endif
-// The per-lane walk (walk_lanes) serves dense grids (C5: 37 entries per cell; the plain kernel variant); sparse grids (C3: 3.6 per
-// cell) take the pooled walk (walk_pool, the variant k_render<true,0,4>).
-// grid entries tested per step of the per-lane walk (loads in flight together).  C5 4: 144.8 ms, 6: 133.5, 8: 129.6
-#ifndef RT_BATCH_DENSE
-#define RT_BATCH_DENSE 8
-#endif
-// phase B of the per-lane walk starts when holders * VOTE >= searchers (or nobody searches) (C5: 2 -> 126 ms, 3 -> 122, 5 -> 120)
-#ifndef RT_VOTE_DENSE
-#define RT_VOTE_DENSE 5
-#endif
-// a pixel averaging at least this many bounces per sample is a long chain (the scene average is ~2.7)
-#ifndef RT_LONG_RATE
-#define RT_LONG_RATE 14
-#endif
-#ifndef RT_LONG_RATE_DENSE
-#define RT_LONG_RATE_DENSE 20    // the dense-grid variant is bound by throughput, not by its chains: C5 663 ms (14: 668)
-#endif
-// at most 1/RT_THIN_CAP_DEN of the resident waves may be thin at a time
-#ifndef RT_THIN_CAP_DEN
-#define RT_THIN_CAP_DEN 4
-#endif
-// waves with at most this many rays on the fast path walk the grid cooperatively (lanes = spheres; 1, 2 or 4 rays at a time)
-// a pixel averaging at least this many bounces per sample (below RT_LONG_RATE) is a medium chain: its wave keeps refilling
-// but issues at priority 1 — the frame is as long as these chains are slow; 0 = off.  C3: off 22.88 ms,
-// 10: 22.62, 12: 22.51, 15: 22.53; priority 2 instead of 1: the same
-#ifndef RT_MED_RATE
-#define RT_MED_RATE 12
-#endif
-#ifndef RT_COOP_MAX
-#define RT_COOP_MAX 8           // dense grids only (see closest_tree)
-#endif
-// phase-A iterations a wave spends on its lanes' walks per bounce iteration before unfinished walks are postponed (0 = no cap)
-#ifndef RT_WALK_CAP
-#define RT_WALK_CAP 0      // measured: capping costs more main-loop iterations than it saves walk steps (cap 2: +32 %, 4: +8 %, 6: +1 %)
-#endif
-// A per-lane walk returns once only 1/RT_QUORUM_DEN of the lanes that entered it are still walking (in waves that entered
-// with >= RT_QUORUM_MIN walkers): the stragglers keep their position (TreeState) and resume on the next call, together
-// with the new rays of the lanes that went on to shade.  Measured on C3: off 32.3 ms, 2: 31.8, 4: 31.2, 8: 30.6, 16: 31.1.
-// On dense grids walks are long and uneven, leaving earlier pays: C5 off 134.8 ms, 1/16: 126.1, 1/8: 122.1, 1/4: 118.5, 1/2: 114.3.
-#ifndef RT_QUORUM_SPARSE
-#define RT_QUORUM_SPARSE 4      // (walk_pool, round 2: 8: 20.41 ms, 4: 19.94, 3: 19.91, 2: 20.14, off: 21.06)
-#endif
-#ifndef RT_QUORUM_DENSE
-#define RT_QUORUM_DENSE 2
-#endif
-#ifndef RT_QUORUM_MIN
-#define RT_QUORUM_MIN 16
-#endif
-
-// pilot classification: the pixels of a 2x2 block are started as long chains when the pilot bounces of the block and its eight
-// neighbours (RT_PILOT_SAMPLES samples each) total at least RT_PILOT_LONG_SUM.  Measured on C3 against the chains' true lengths
-// (tools/predictor.py): a block's own pilot >= 50 finds 22 % of the pixels above 1280 iterations and 62 % of those above 2000;
-// the 3x3 sum >= 200 finds 86 % and 100 %, and 1 % of what it selects is shorter than 400 iterations.
-#ifndef RT_PILOT_SAMPLES
-#define RT_PILOT_SAMPLES 2
-#endif
-#ifndef RT_PILOT_LONG_SUM
-#define RT_PILOT_LONG_SUM 200
-#endif
-#ifndef RT_PILOT_CAP
-#define RT_PILOT_CAP 35     // bounces after which a pilot sample is cut (the pilot pass is as long as its longest chain; 50 = the reference's depth limit)
-#endif
-// long chains started per thin wave
-#ifndef RT_GROUND_SHORT
-#define RT_GROUND_SHORT 1      // skip the exact ground test for rays that leave the ground behind (exact, see closest_tree)
-#endif
-#ifndef RT_LONG_CHECK
-#define RT_LONG_CHECK 4         // a pixel's bounce rate is looked at every so many samples (a power of two; 8 with rate 20: C3 17.85 ms, 4 / 20: 17.55, 4 / 16: 17.2, 4 / 14: 16.93, 4 / 13: 17.17, 4 / 12: 17.6, 8 / 14: 17.5, 2 / 20: 17.9)
-#endif
-#ifndef RT_LONG_STRIDE
-#define RT_LONG_STRIDE 1
-#endif
-#ifndef RT_PROG_CHUNKED
-#define RT_PROG_CHUNKED 1       // progressive passes take their pixel slots in chunks per wave (see k_render: take_slot)
-#endif
-#ifndef RT_PROG_OWN
-#define RT_PROG_OWN 64          // ... after a share of its own per wave (C3, ms per pass: 0: 0.645, 64: 0.567, 128: 0.611)
-#endif
-#ifndef RT_LONG_PER_WAVE
-#define RT_LONG_PER_WAVE 16     // (4 with the per-lane walk; the pooled walk serves a thin wave of 16 chains: 2: 20.32 ms, 4: 20.04, 8: 19.84, 16: 19.81, 32: 21.92)
-#endif
-// list path: rays are scanned cooperatively (lanes = spheres) while live_rays * RT_LIST_COOP_COST <= list size
-// list path: spheres per pass of the linear scan
-#ifndef RT_LIST_BATCH
-#define RT_LIST_BATCH 8
-#endif
-#ifndef RT_LIST_TREE_COOP
-#define RT_LIST_TREE_COOP 1
-#endif
-#ifndef RT_LIST_COOP_COST
-#define RT_LIST_COOP_COST 16
-#endif
-
-// Diagnostic build only (-DRT_STATS, tools/stats.sh): per-lane work counters, summed into a global array at kernel end.
-#ifdef RT_STATS
-enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFERS, ST_ELIG, ST_ELIG_NODES, ST_A_ITERS_WAVE, ST_B_ROUNDS_WAVE,
-       ST_LOOP_ITERS_WAVE, ST_A_LANE_STEPS, ST_B_LANES, ST_SAMPLES, ST_LIVE_GE56, ST_LIVE_32, ST_LIVE_8, ST_LIVE_LT8, ST_SWITCHES,
-       ST_CYC_TOTAL, ST_CYC_CLOSEST, ST_CYC_WALK_A, ST_CYC_WALK_B, ST_CYC_SCAN, ST_CYC_SHADE, ST_REALTIME,
-       ST_SPARE0, ST_SPARE1, ST_SPARE2, ST_SPARE3, ST_SPARE4, ST_SPARE5, ST_SPARE6,
-       // wave passes: how often a wave (any lane) executed a block — multiplied by the block's static size = issue slots
-       WP_GROUND, WP_LARGE_K, WP_LARGE_EXACT, WP_OFFER_NODE, WP_OFFER_RAYBOX, WP_ELIG_FN, WP_ELIG_LIST, WP_SETUP, WP_A_COL, WP_A_BATCH, WP_A_HOLD,
-       WP_B_OFFER, WP_B_CLIP, WP_COOP_CHUNK, WP_SCAN, WP_SC_ANY, WP_SC_LAMB, WP_SC_METAL, WP_SC_DIEL, WP_REJ_ITER, WP_PRIMARY, WP_DISK_ITER, WP_SKY, WP_ENDPIX,
-       // cycles of the iterations of thin waves with <= 2 live lanes, by part (the critical path of the frame's tail)
-       TH_GROUND, TH_LARGE_SETUP, TH_WALK, TH_SCAN, ST_N };
-#define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
-__device__ unsigned long long g_stats[ST_N];
-__device__ int g_pilot_dbg[1 << 20];                  // per 2x2 block (tile * 16 + block): the pilot's bounce count
-__device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
-struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
-#define STAT(st, k, v) ((st).c[k] += (v))
-#ifdef RT_STATS_WPASS      // (the atomics distort every timing of the same run: a build of its own, librt_amd_wpass.so)
-#define WPASS(k) do { const int l_ = (int)(threadIdx.x & 63); if (__builtin_amdgcn_readfirstlane(l_) == l_) atomicAdd(&g_stats[k], 1ull); } while (0)
-#else
-#define WPASS(k) ((void)0)
-#endif
-#define STAT_ARG , Stats& st
-#define STAT_PASS , st
-#else
-#define STAT(st, k, v) ((void)0)
-#define WPASS(k) ((void)0)
-#define STAT_ARG
-#define STAT_PASS
-#endif
+#include "rt_stats.h"      // the diagnostic build's counters (-DRT_STATS): STAT / WPASS / RT_STATS_ONLY — nothing in a product build
 
 struct Rng { uint32_t d, v0, v1, v2, v3, v4; };
 
@@ -358,7 +230,7 @@ RT_DEV void closest_list(const DevScene& S, const RayF& r, float a, bool live, f
 // passes the slab test, then scans that node's entries.  `closest`/`best` come in holding the ground-sphere result.
 RT_DEV void tree_scan(const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best) {
     const DevTree& T = cold_args()->tree;
-    if (RT_LIST_TREE_COOP && T.n_nodes == 1) {
+    if (T.n_nodes == 1) {
         // the list seen as one unbounded node (rt_api.hip build_list_tree): all n_entries spheres are this ray's to test.  Few
         // rays come here (outside the near zone, ties), so one at a time with lanes = spheres as in closest_list — the smallest
         // offered t, the lowest entry among equal t, and only if it beats what the ray holds (the ground was tested first)
@@ -501,11 +373,9 @@ RT_DEV void offer(const DevTree& T, const float4* s_nodes, const RayF& r, float 
 }
 
 // Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
-// clipped to the y-slab that holds them, front to back, ending at the column that lies beyond the best hit.
-// The walk alternates two phases so that the expensive, rare work is done by many lanes at once:
-//   A  every lane steps through its columns / entries (18-op discriminant only) until it holds a sphere with disc > 0;
-//   B  the lanes holding one take the roots (sqrt, divide) and, if it would win, the reference's slab test (eligible()).
-// Returns true when the result must be recomputed by the reference scan (exact tie between two tree spheres).
+// clipped to the y-slab that holds them, front to back, ending at the column that lies beyond the best hit.  The walks
+// (walk_pool for sparse grids, walk_pool_dense for dense ones) pool the sphere tests of a wave's rays and deal them out evenly
+// over its 64 lanes; an exact tie between two tree spheres sends the ray to the reference scan.
 struct Walk {                // a ray's walk over the grid, in cell units along its major axis
     int i, iend, coff;      // next column, end (exclusive, in travel direction), offset of the x- or z-major grid copy
     float om_c, on_c, slope, dm_c;
@@ -568,290 +438,17 @@ RT_DEV void column_range(const DevAccel& A, const Walk& W, int col, int& e0, int
     }
 }
 
-// Cooperative walk for waves with only a few rays (thin waves: DESIGN.md §5.4).  One ray at a time, all 64 lanes: up to 8
-// columns' cell ranges are fetched at once, their entries are spread over the lanes, every lane tests ONE sphere, the
-// lanes holding a possible winner take the exact roots and the reference's slab test in parallel, and a wave-wide
-// minimum picks the hit.  Three memory round trips per chunk instead of one per step.  Same result as the per-lane walk:
-// the minimum over the eligible candidates; an exact tie between two different spheres sends the ray to the reference scan.
-RT_DEV void walk_coop(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, bool mine, float& best_t, int& best, bool& tie STAT_ARG) {
-    const DevAccel& A = T.acc;
-    const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(mine && W.walking);
-    while (todo != 0ull) {
-        const int L = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        RayF q;                                              // lane L's ray, in every lane
-        q.o.x = bcast(r.o.x, L); q.o.y = bcast(r.o.y, L); q.o.z = bcast(r.o.z, L);
-        q.d.x = bcast(r.d.x, L); q.d.y = bcast(r.d.y, L); q.d.z = bcast(r.d.z, L);
-        const float qa = bcast(a, L);
-        Walk Q;
-        Q.i = bcast(W.i, L); Q.iend = bcast(W.iend, L); Q.coff = bcast(W.coff, L);
-        Q.om_c = bcast(W.om_c, L); Q.on_c = bcast(W.on_c, L); Q.slope = bcast(W.slope, L); Q.dm_c = bcast(W.dm_c, L);
-        Q.fwd = bcast((int)W.fwd, L) != 0; Q.walking = true;
-        float bt = bcast(best_t, L); int bi = bcast(best, L);
-        bool tieL = false;
-        const int stp = Q.fwd ? 1 : -1;
-        const float ra = __builtin_amdgcn_rcpf(qa);
-        while (Q.i != Q.iend) {
-            STAT(st, ST_A_ITERS_WAVE, 1); WPASS(WP_COOP_CHUNK);
-            const int left = Q.fwd ? (Q.iend - Q.i) : (Q.i - Q.iend);
-            const int ncol = left < 8 ? left : 8;
-            int eb = 0, cnt = 0;
-            if (lane < ncol) { int e1; column_range(A, Q, Q.i + lane * stp, eb, e1); cnt = e1 - eb; }
-            int incl = cnt;                                  // inclusive prefix over lanes 0..7
-            { incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); }   // row_shr:1,2,4 (the 8 lanes sit in one row of 16)
-            const int total = bcast(incl, 7);
-            for (int base = 0; base < total; base += 64) {
-                const int jdx = base + lane;
-                const bool have = jdx < total;
-                int e = 0;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int inc_m = bcast(incl, m), cnt_m = bcast(cnt, m), eb_m = bcast(eb, m);
-                    if (jdx >= inc_m - cnt_m && jdx < inc_m) e = eb_m + (jdx - (inc_m - cnt_m));
-                }
-                float cand = __builtin_inff();
-                bool want = false;
-                // the candidate's brick is fetched together with its sphere: a cooperative walk serves a wave that has nothing
-                // to hide a dependent L2 round trip behind (bandwidth is no concern there)
-                float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
-                if (have) {
-                    STAT(st, ST_TESTS, 1);
-                    const float4 s = A.hot[e];
-                    blo = A.brick[2 * e]; bhi = A.brick[2 * e + 1];
-                    const float ocx = q.o.x - s.x, ocy = q.o.y - s.y, ocz = q.o.z - s.z;
-                    const float b = ocx * q.d.x + ocy * q.d.y + ocz * q.d.z;
-                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
-                    const float disc = b * b - qa * c;
-                    if (disc > 0.0f) {
-                        const float sqa = __builtin_amdgcn_sqrtf(disc);
-                        const float m = 1e-4f * ((fabsf(b) + sqa) * ra) + 1e-6f;
-                        const bool behind = (sqa - b) * ra + m < 0.001f;
-                        const bool beyond = (-b - sqa) * ra - m > bt;
-                        if (!behind && !beyond) {
-                            const float sq = sqrtf(disc);
-                            const float t1 = (-b - sq) / qa;
-                            if (t1 > 0.001f) cand = t1;
-                            else { const float t2 = (-b + sq) / qa; if (t2 > 0.001f) cand = t2; }
-                            want = cand <= bt;
-                        }
-                    }
-                }
-                if (__ballot(want) != 0ull) {
-                    STAT(st, ST_B_ROUNDS_WAVE, 1);
-                    int id = -1;
-                    bool elig = false;
-                    if (want) {
-                        id = __float_as_int(blo.w);
-                        if (cand < bt) {
-                            elig = in_brick(q, cand, blo, bhi);
-                            if (!elig) {
-                                const int nd = __float_as_int(bhi.w);
-                                if (nd >= 0) {
-                                    const float4 n0 = s_nodes[nd * 3 + 0]; const float4 n1 = s_nodes[nd * 3 + 1];
-                                    elig = ray_box(q, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
-                                }
-                                else elig = eligible(s_nodes, q, cand, id STAT_PASS);
-                            }
-                        }
-                    }
-                    // an equal t from a different tree sphere than the current best: the visit order would decide
-                    if (__ballot(want && cand == bt && id != bi && bi > 0) != 0ull) tieL = true;
-                    const float mn = group_min<64>(elig ? cand : __builtin_inff());
-                    if (mn < bt) {
-                        const unsigned long long mm = __ballot(elig && cand == mn);
-                        const int wid = bcast(id, __ffsll((long long)mm) - 1);
-                        if (__ballot(elig && cand == mn && id != wid) != 0ull) tieL = true;
-                        bt = mn; bi = wid;
-                    }
-                }
-            }
-            Q.i += ncol * stp;
-            if (bi >= 0) walk_clip(Q, A, bt);
-        }
-        if (lane == L) { best_t = bt; best = bi; tie = tie || tieL; W.walking = false; }
-    }
-}
-
-
-// Fast path: large spheres directly, small spheres through the (x,z) grid along the ray's projection,
-// clipped to the y-slab that holds them, front to back, ending at the column that lies beyond the best hit.
-// The per-lane walk alternates two phases so that the expensive, rare work is done by many lanes at once:
-//   A  every lane steps through its columns / entries (18-op discriminant only) until it holds a sphere with disc > 0;
-//   B  the lanes holding one take the roots (sqrt, divide) and, if it would win, the reference's slab test (eligible()).
-// `tie` is set when the result must be recomputed by the reference scan (exact tie between two tree spheres).
-// `budget` > 0: return after that many phase-A iterations even if some lanes have not finished; their position is left
-// in W (W.walking stays true) and the walk is resumed by the next call.
-template <int RT_BATCH, int RT_QUORUM_DEN, int RT_VOTE_NUM>
-RT_DEV void walk_lanes(const DevTree& T, const float4* s_nodes, const RayF& r, float a, Walk& W, int& e, int& e_end, int budget, float& best_t, int& best, bool& tie STAT_ARG) {
-    const DevAccel& A = T.acc;
-    const int32_t* __restrict__ cs = A.cs;
-    const float4* __restrict__ hot = A.hot;
-    // The loop below is short of SGPRs (the compiler spills them to VGPR lanes and reloads whole 8-register tuples inside
-    // the loop, each reload a VALU slot): the grid size is kept in a VGPR instead, there are plenty of those.
-    int G = A.G;
-    asm volatile("" : "+v"(G));
-    const float fG = (float)G;
-    float s_c = 2e-3f * A.inv_h;
-    asm volatile("" : "+v"(s_c));
-    const float om_c = W.om_c, on_c = W.on_c, slope = W.slope;
-    const int coff = W.coff;
-    const bool fwd = W.fwd;
-    const int step = fwd ? 1 : -1;
-    int i = W.i, iend = W.iend;
-    bool walking = W.walking;
-    auto clip_to_hit = [&]() { W.i = i; W.iend = iend; walk_clip(W, A, best_t); i = W.i; iend = W.iend; };
-    // pre-filter thresholds (see phase A): a(1+kap) t_best + 1e-6 a, refreshed when the best hit changes, and a(1-kap) t_min - 1e-6 a
-    float f_abt = __builtin_fmaf(a * best_t, 1.0001f, 1e-6f * a);
-    const float f_atm = a * (0.001f * 0.9999f - 1e-6f);
-    int ne = 0, ne_end = 0;                                  // prefetched entry range of column i (the next one to enter)
-    int used = 0;                                            // phase-A iterations of this call (wave-uniform)
-    float p_b = 0.0f, p_disc = 0.0f; int p_e = -1;          // the sphere this lane holds for phase B
-    float4 p_lo = make_float4(0.f, 0.f, 0.f, 0.f), p_hi = p_lo;
-    // A thin wave has nothing to hide an L2 round trip behind (~1000 cycles per dependent load), and the frame cannot end
-    // before its longest pixel chain does — so the walk keeps several loads in flight: the cell range of the next
-    // column is fetched while the current column's entries are tested, and entries are tested four at a time.
-    const float fGm = fG - 0.5f;
-    auto prefetch_col = [&]() {
-        // minor-axis extent of the line inside column i: lower edge at i, upper edge at i+1
-        const float u0 = on_c + ((float)i - om_c) * slope, u1 = u0 + slope;
-        const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-        ne = 0; ne_end = 0;
-        if (hi >= 0.0f && lo < fG) {                          // cells max(floor(lo), 0) .. min(floor(hi), G-1)
-            const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGm);
-            const unsigned cbase = (unsigned)(coff + i * G);
-            ne = cs[cbase + (unsigned)k0];
-            ne_end = cs[cbase + (unsigned)k1 + 1u];
-        }
-    };
-    if (walking && i != iend) prefetch_col();
-    const int nw0 = __popcll(__ballot(walking));
-    bool leave = false;
-    while (true) {
-        if ((budget > 0 && used >= budget) || leave) break;
-        // ---- phase A (wave-uniform loop): lanes without a held sphere take one step per iteration; the wave moves
-        //      on to phase B as soon as the holders are numerous enough to make the expensive code worthwhile
-        while (true) {
-            const bool searching = walking && (p_e < 0);
-            const unsigned long long ms = __ballot(searching), mp = __ballot(p_e >= 0);
-            if (ms == 0ull || __popcll(mp) * RT_VOTE_NUM >= __popcll(ms) || (budget > 0 && used >= budget)) break;
-            if (RT_QUORUM_DEN > 0 && nw0 >= RT_QUORUM_MIN && (int)(__popcll(ms) + __popcll(mp)) * RT_QUORUM_DEN <= nw0) { leave = true; break; }
-            ++used;
-            STAT(st, ST_A_ITERS_WAVE, 1);
-            if (searching) {
-                STAT(st, ST_A_LANE_STEPS, 1);
-                if (e >= e_end && i != iend) {                 // enter the next column (its range was fetched a step ago)
-                    STAT(st, ST_COLS, 1); WPASS(WP_A_COL);
-                    e = ne; e_end = ne_end;
-                    i += step;
-                    if (i != iend) prefetch_col();
-                }
-                if (e < e_end) {
-                    // RT_BATCH entries per step, loads in flight together.  The loads over-read past e_end (the arrays are
-                    // padded): those entries belong to later cells or are NaN padding, and testing a sphere the walk would
-                    // not have visited cannot change the result (it cannot be a legitimate closer hit) — but only entries
-                    // of this range may be held.
-                    const float4* __restrict__ hp = hot + e;
-                    const int rem = e_end - e;
-                    STAT(st, ST_TESTS, rem < RT_BATCH ? rem : RT_BATCH); WPASS(WP_A_BATCH);
-                    float4 s4[RT_BATCH];
-#pragma unroll
-                    for (int k = 0; k < RT_BATCH; ++k) s4[k] = hp[k];
-                    // Cheap pre-filter for the whole batch.  A sphere whose far root is surely <= t_min, or whose near root
-                    // is surely >= the best hit, is rejected by sphere::hit whatever its float roots are.  With S = sqrt(disc)
-                    // the float roots differ from (-b -+ S)/a by at most 3.1 u (|b| + S)/a; the tests below leave a margin of
-                    // kap (|b| + S)/a + 1e-6, kap = 1e-4 (~500x), and need no square root:
-                    //   near root beyond:  -b - kap|b| - a(1+kap) t_best - 1e-6 a  >  (1+kap) S   <=  L > 0 and L^2 > (1+3kap) disc
-                    //   far root behind:    b - kap|b| + a(1-kap) t_min  - 1e-6 a  >  (1+kap) S   <=  M > 0 and M^2 > (1+3kap) disc
-                    // (DESIGN.md App. A.5).  The first sphere of the batch that survives is held for phase B, the entries
-                    // after it are examined again later.
-                    int kf = RT_BATCH; float bf = 0.0f, df = 0.0f;
-#pragma unroll
-                    for (int k = RT_BATCH - 1; k >= 0; --k) {
-                        const float ocx = r.o.x - s4[k].x, ocy = r.o.y - s4[k].y, ocz = r.o.z - s4[k].z;
-                        const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
-                        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4[k].w;
-                        const float disc = b * b - a * c;
-                        const float ab = fabsf(b);                      // (L and M are never both positive: one test of the larger, see walk_pool)
-                        const float L = __builtin_fmaf(ab, -1e-4f, -b) - f_abt, M = __builtin_fmaf(ab, -1e-4f, b) + f_atm;
-                        const float P = fmaxf(L, M);
-                        if (disc > 0.0f && k < rem && !(P > 0.0f && P * P > disc * 1.0003f)) { kf = k; bf = b; df = disc; }
-                    }
-                    if (kf < RT_BATCH) {
-                        p_b = bf; p_disc = df; p_e = e + kf;
-                        p_lo = A.brick[2 * (e + kf)]; p_hi = A.brick[2 * (e + kf) + 1];       // in flight until phase B
-                        STAT(st, ST_DISCPOS, 1); WPASS(WP_A_HOLD);
-                        e += kf + 1;
-                    } else {
-                        e += RT_BATCH;
-                    }
-                } else if (i == iend) {
-                    walking = false;
-                }
-            }
-        }
-#ifdef RT_STATS
-        const unsigned long long tB0 = TICK();
-#endif
-        if (__ballot(p_e >= 0) == 0ull) break;                 // nobody holds a sphere and nobody is searching
-        STAT(st, ST_B_ROUNDS_WAVE, 1);
-        if (p_e >= 0) {
-        STAT(st, ST_B_LANES, 1);
-        // ---- phase B: roots of the held sphere (sphere.h:24-43), then the offer
-        const float sq = sqrtf(p_disc);
-        float cand = __builtin_inff();
-        const float t1 = (-p_b - sq) / a;
-        if (t1 > 0.001f) cand = t1;
-        else {
-            const float t2 = (-p_b + sq) / a;
-            if (t2 > 0.001f) cand = t2;
-        }
-        if (cand <= best_t) {
-            const float before = best_t;
-            WPASS(WP_B_OFFER);
-            offer(T, s_nodes, r, cand, p_lo, p_hi, best_t, best, tie STAT_PASS);
-            if (best_t < before) {
-                WPASS(WP_B_CLIP);
-                f_abt = __builtin_fmaf(a * best_t, 1.0001f, 1e-6f * a);
-                clip_to_hit();
-                if (fwd ? (i >= iend) : (i <= iend)) { i = iend; }
-            }
-        }
-        p_e = -1;
-        }
-#ifdef RT_STATS
-        st.cyc[6] += TICK() - tB0;
-#endif
-    }
-    // leave the position behind: next column, end column and the untested rest [e, e_end) of the current column
-    W.i = i; W.iend = iend;
-    W.walking = walking && (e < e_end || i != iend);
-    if (!W.walking) { e = 0; e_end = 0; }
-}
-
 // ---------------------------------------------------------------------------------------------------- the walk of a full wave
-// walk_lanes above lets every lane test the spheres of ITS columns: 47 % of the lanes busy, 3.5 of 6 test slots used, lanes
-// holding a candidate waiting for the vote.  walk_pool spreads the wave's sphere tests evenly instead (the scheme of the
-// binary16 scan, rt_kernels_fp16.hip): per round every walking lane puts the entry ranges of its next RT_POOL_COLS columns
+// Letting every lane test the spheres of ITS columns (rounds 1-2: walk_lanes, removed in round 3 with the cooperative single-ray
+// walk once no launch reached them) ran at 47 % busy lanes, 3.5 of 6 test slots used, lanes holding a candidate waiting for a
+// vote.  walk_pool spreads the wave's sphere tests evenly instead (the scheme of the binary16 scan, rt_kernels_fp16.hip): per round every walking lane puts the entry ranges of its next RT_POOL_COLS columns
 // into the wave's pool (LDS); a prefix over the ranges and a binary search give every lane an equal span of the concatenated
 // entries, which it tests — 18-operation discriminant and square-root-free pre-filter as in phase A — against the OWNER's ray
 // (LDS) whoever that is; survivors go into a queue of the wave and are resolved 64 at a time (exact roots, brick / slab
 // eligibility as in phase B), the owner's best hit kept as a 64-bit key (t bits << 32 | sphere index) by an LDS atomic
 // min.  An atomic min that meets an equal t from another sphere flags the exact tie (-> reference scan), as `offer` does.
 // Nothing here decides a hit differently: the same candidates' exact values, merged by a minimum instead of one after the other;
-// testing MORE spheres than walk_lanes would (no clipping inside a round) cannot change the minimum (App. A.4).
-#ifndef RT_POOL_COLS
-#define RT_POOL_COLS 2
-#endif
-#ifndef RT_PILOT_POOL
-#define RT_PILOT_POOL 1
-#endif
-#ifndef RT_POOL_SPANS
-#define RT_POOL_SPANS 1
-#endif
-#ifndef RT_POOL_COLS_THIN
-#define RT_POOL_COLS_THIN 4
-#endif
+// testing MORE spheres than a clipped per-ray walk would (no clipping inside a round) cannot change the minimum (App. A.4).
 static_assert(RT_POOL_COLS_THIN >= RT_POOL_COLS, "a thin round takes at least as many columns as a full one");
 constexpr int kWalkPool = 64 * RT_POOL_COLS;                  // segments per wave and round
 constexpr int kWalkCand = 128;
@@ -1106,19 +703,10 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
 }
 
 // The pooled walk for DENSE grids (C5: ~30 entries per cell, 60-100 per column).  One column per walking lane and round; a lane
-// steps through its span RT_DENSE_PB entries at a time (their loads in flight together, like walk_lanes' batches) and filters
+// steps through its span RT_DENSE_PB entries at a time (their loads in flight together) and filters
 // against the owner's CURRENT best hit, re-read from the wave's LDS every pass — on a dense grid most of a column lies behind the
 // first hit, and a filter that only knew the hit of the previous round would send all of it to the candidate queue.  The queue is
 // drained from RT_DENSE_DRAIN candidates on, so that a found hit starts rejecting soon.
-#ifndef RT_DENSE_POOL
-#define RT_DENSE_POOL 1
-#endif
-#ifndef RT_DENSE_PB
-#define RT_DENSE_PB 4
-#endif
-#ifndef RT_DENSE_DRAIN
-#define RT_DENSE_DRAIN 32
-#endif
 template <int RT_QUORUM_DEN>
 RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L, const RayF& r, float a, Walk& W, float& best_t, int& best, bool& tie STAT_ARG) {
     constexpr int PB = RT_DENSE_PB;
@@ -1261,10 +849,12 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
 }
 
 // hitTree (acceleration_structure.h:319-342): ground sphere first, then the tree.
-// The fast path's per-lane walk is bounded per call (RT_WALK_CAP phase-A iterations): a lane whose walk is not finished
-// comes back with ts.pending set and resumes on the next call with the same ray, while the lanes that are done go on to
-// shade and start new rays — the wave no longer waits for its longest walk.  `closest`/`best` persist with the caller.
-struct TreeState { Walk W; int e, e_end; float g_t; int g_id; bool tie, pending; };
+// A pooled walk returns once most of the wave's rays are done (quorum): a lane whose walk is not finished comes back with
+// ts.pending set and resumes on the next call with the same ray, while the lanes that are done go on to shade and start new
+// rays — the wave does not wait for its longest walk.  `closest`/`best` persist with the caller.
+// COOPG selects the walk: 4 = walk_pool (sparse grids), 2 = walk_pool_dense, 1 = none — trees without a candidate grid (and the
+// reference traversal mode) take the literal scan for every ray.
+struct TreeState { Walk W; float g_t; int g_id; bool tie, pending; };
 
 template <int COOPG>
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best, TreeState& ts STAT_ARG) {
@@ -1275,23 +865,19 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         WPASS(WP_GROUND);
         const float4 g = S.list_hot[0];
         int gb = -1;
-#if RT_GROUND_SHORT
         // origin outside the sphere (c > 0) and heading away from its centre (b > 0): disc <= fl(b*b), so sqrt(disc) <= b and
         // both roots are <= 0 — the float test cannot pass (no margin involved); saves the exact sqrt and two divisions
         { const float ocx = r.o.x - g.x, ocy = r.o.y - g.y, ocz = r.o.z - g.z;
           const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
           const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
           if (__ballot(fresh && !(b > 0.0f && c > 0.0f)) != 0ull) sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb); }
-#else
-        sphere_test(r, a, g.x, g.y, g.z, g.w, 0, closest, gb);
-#endif
         if (gb == 0) best = 0;
     }
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     const unsigned long long tG = TICK(); st.cyc[4] += tG;      // (entry stamp is subtracted by the caller's tC0)
-#endif
+    )
     bool slow = fresh;
-    if (T.acc.enabled) {
+    if (COOPG != 1 && T.acc.enabled) {
         // preconditions of the exactness argument; any NaN/inf makes a comparison false and sends the ray to the scan
         const float zx = r.o.x, zy = r.o.y - 1.0f, zz = r.o.z;
         const bool fast = fresh && (a >= 9.094947e-13f) && (a <= 1.0995116e12f) && (r.d.x != 0.0f) && (r.d.z != 0.0f)
@@ -1327,56 +913,35 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             }
             WPASS(WP_SETUP);
             ts.W = walk_setup(T.acc, r, closest, best);
-            ts.e = 0; ts.e_end = 0;
         }
-#ifdef RT_STATS
+        RT_STATS_ONLY(
         const unsigned long long tL = TICK(); st.cyc[5] += tL - tG;       // large spheres + walk set-up
-#endif
+        )
         const bool walker = fast || (live && ts.pending);
         const int nw = __popcll(__ballot(walker));
-        // the cooperative walk starts at a column boundary: not while a lane has a partly tested column
-        // the plain variant (per-lane walk): a wave with few walkers resolves them cooperatively, one ray at a time with lanes = spheres
-        // (the pooled variants serve a wave of one ray as well as a full one: with cooperative walks C5 723.7 against 723.9 ms).
-        // Sparse grids (the pooled variant) pool the walks of any number of rays: measured with cooperative walks for <= 8 rays 20.41 ms,
-        // <= 2: 20.27, none: 19.94 — and without that code the kernel fits four waves per SIMD (19.51 ms)
-        const bool coop = nw > 0 && nw <= (COOPG == 1 ? RT_COOP_MAX : COOPG == 2 ? 0 : RT_COOP_SPARSE) && __ballot(walker && ts.e < ts.e_end) == 0ull;
-        if (coop) {
-            const int lane_ = threadIdx.x & 63;
-            unsigned long long todo = __ballot(walker && ts.W.walking);
-            while (todo != 0ull) {
-                const int L = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                walk_coop(T, s_nodes, r, a, ts.W, lane_ == L, closest, best, ts.tie STAT_PASS);
-            }
-        }
-        else if (COOPG >= 4 && nw > 0) {      // sparse grids (on dense ones — C5: 37 entries per cell, ~100 per column — this walk filters against a stale best hit: 1754 ms with two columns per round, 1281 with one, against 817 for the per-lane walk; they take walk_pool_dense)
+        if (nw > 0) {
             // every lane of the wave takes part: lanes without a walk of their own test other lanes' spheres
             WalkLds& L = *((WalkLds*)(s_nodes + T.n_nodes * 3) + (threadIdx.x >> 6));
             Walk Wl = ts.W; Wl.walking = walker && ts.W.walking;
             float bt = walker ? closest : FLT_MAX; int bi = walker ? best : -1; bool tt = false;
-            walk_pool<(COOPG >= 4 ? RT_QUORUM_SPARSE : RT_QUORUM_DENSE)>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
+            // (sparse grids — C3: 3.6 entries per cell — pool two columns per ray and round; on dense ones — C5: 37 per cell, ~100
+            // per column — that walk filters against a stale best hit: 1281 ms against 670 for walk_pool_dense, which re-reads it)
+            if (COOPG >= 4) walk_pool<RT_QUORUM_SPARSE>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
+            else walk_pool_dense<RT_QUORUM_DENSE>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
             if (walker) { ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
         }
-        else if (RT_DENSE_POOL && COOPG == 2 && nw > 0) {
-            WalkLds& L = *((WalkLds*)(s_nodes + T.n_nodes * 3) + (threadIdx.x >> 6));
-            Walk Wl = ts.W; Wl.walking = walker && ts.W.walking;
-            float bt = walker ? closest : FLT_MAX; int bi = walker ? best : -1; bool tt = false;
-            walk_pool_dense<RT_QUORUM_DENSE>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
-            if (walker) { ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
-        }
-        else if (!(RT_DENSE_POOL && COOPG == 2) && walker) walk_lanes<RT_BATCH_DENSE, RT_QUORUM_DENSE, RT_VOTE_DENSE>(T, s_nodes, r, a, ts.W, ts.e, ts.e_end, RT_WALK_CAP, closest, best, ts.tie STAT_PASS);
         if (walker) {
             ts.pending = ts.W.walking;
             if (!ts.pending && ts.tie) { closest = ts.g_t; best = ts.g_id; slow = true; STAT(st, ST_TIE, 1); }
         }
     }
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     const unsigned long long tS0 = TICK(); st.cyc[1] += tS0 - tG;     // fast path (large spheres + setup + walk), wave time
-#endif
+    )
     if (__ballot(slow) != 0ull) { WPASS(WP_SCAN); tree_scan(s_nodes, r, a, slow, closest, best); }
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     st.cyc[3] += TICK() - tS0;
-#endif
+    )
 }
 
 // ---------------------------------------------------------------------------------------------------- sampling
@@ -1563,17 +1128,17 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
     int sample = 0, depth = 0;
     bool live = false;
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     unsigned int pix_iters = 0;
     unsigned long long pix_t0 = 0;
-#endif
+    )
 
     // The next unclaimed slot.  render: one request to the global work counter per lane and pixel (a pixel is ns samples: requests are
     // rare, and the fine grain balances the frame's tail).  render_progressive hands out a pixel per lane and BOUNCE or so: 1.2 M
     // requests per C3 pass, one atomic per wave and iteration on one address — 0.3 ms of a 1.0 ms pass.  There a wave owns its first
     // kProgOwn slots outright (the counter's values start behind all waves' own slots) and then takes the rest in chunks of 64, at
     // the one place of the main loop where the wave is convergent (`refill_progressive`).
-    constexpr bool kChunked = (MODE == 1) && RT_PROG_CHUNKED;
+    constexpr bool kChunked = MODE == 1;
     constexpr long long kProgOwn = RT_PROG_OWN;
     const long long first_free = (kChunked && kProgOwn > 0 && n_waves * kProgOwn <= n_slots) ? n_waves * kProgOwn : 0;
     long long pool_next = 0, pool_end = 0;              // wave-uniform: this wave's current chunk [pool_next, pool_end)
@@ -1605,9 +1170,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             if (i < A.max_x && j < A.max_y && !taken) {
                 idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l;
                 live = true;
-#ifdef RT_STATS
+                RT_STATS_ONLY(
                 pix_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+                )
                 break;
             }
             slot = take_slot();
@@ -1629,12 +1194,8 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         // the list is in the pilot's order, the four pixels of a 2x2 block and the blocks of a tile next to each other — and
         // neighbours are chains of like length: a stride (a prime that does not divide the count, so a permutation) puts
         // them into different waves, where each is left alone with its wave once the shorter ones have ended
-#if RT_LONG_STRIDE
         const unsigned int stride = n_long % 257u ? 257u : (n_long % 263u ? 263u : 269u);
         const long long pid = (long long)A.long_list[(unsigned int)(((unsigned long long)h * stride) % n_long)];
-#else
-        const long long pid = (long long)A.long_list[h];
-#endif
         const long long local_tile = pid >> 6;
         const int l = (int)(pid & 63);
         const long long tile = A.part + local_tile * A.nparts;
@@ -1642,9 +1203,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
         idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
         live = true; iters = 0; is_long = true;
-#ifdef RT_STATS
+        RT_STATS_ONLY(
         pix_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+        )
         const rt_rand_state* st = A.rand_state + idx;
         s.d = st->d; s.v0 = st->v[0]; s.v1 = st->v[1]; s.v2 = st->v[2]; s.v3 = st->v[3]; s.v4 = st->v[4];
         col = {0.0f, 0.0f, 0.0f}; att = {1.0f, 1.0f, 1.0f}; sample = 0; depth = 0;
@@ -1661,23 +1222,23 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             const float k = (float)(1.0 / (double)(float)A.ns);          // vec3::operator/=(real_t): 1.0/t in double (vec3.h:137)
             col.x *= k; col.y *= k; col.z *= k;
             fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
-#ifdef RT_STATS
+            RT_STATS_ONLY(
             // diagnostic build: chain length and end / start time (100 MHz ticks mod 2^24) instead of colour
             fb[0] = (float)pix_iters; fb[1] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffffull); fb[2] = (float)(pix_t0 & 0xffffffull);
-#endif
+            )
         } else {
             if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
             else { fb[0] += col.x; fb[1] += col.y; fb[2] += col.z; }
         }
     };
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
     const unsigned long long tK0 = TICK(), rK0 = __builtin_amdgcn_s_memrealtime();
     unsigned int dbg_thin_iters = 0, dbg_long = 0;
     unsigned long long th[4] = {0, 0, 0, 0};
     unsigned long long dbg_thin_cyc = 0, dbg_thin_closest = 0, dbg_thin1_cyc = 0; unsigned int dbg_thin1_iters = 0; unsigned long long dbg_t_prev = TICK();
-#endif
+    )
     // start: pre-classified long chains first, RT_LONG_PER_WAVE per wave, in waves that are thin from the beginning
     if (lane < RT_LONG_PER_WAVE) begin_long_pixel();
     if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
@@ -1685,7 +1246,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 
     const unsigned int thin_cap = (unsigned int)(n_waves / RT_THIN_CAP_DEN);
     float closest = FLT_MAX; int best = -1;
-    TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
+    TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1;
     ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
     while (true) {
         // ---- wave-level bookkeeping (uniform)
@@ -1729,28 +1290,28 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         if (__ballot(live) == 0ull) break;
         (void)m_live;
         STAT(st, ST_LOOP_ITERS_WAVE, 1);
-#ifdef RT_STATS
+        RT_STATS_ONLY(
         { const unsigned long long now = TICK(); const int nl2 = __popcll(__ballot(live));
           if (thin) { ++dbg_thin_iters; dbg_thin_cyc += now - dbg_t_prev; if (nl2 <= 2) { ++dbg_thin1_iters; dbg_thin1_cyc += now - dbg_t_prev; } }
           dbg_t_prev = now; }
-#endif
-#ifdef RT_STATS
+        )
+        RT_STATS_ONLY(
         { const int nl = __popcll(__ballot(live)); STAT(st, nl >= 56 ? ST_LIVE_GE56 : nl >= 32 ? ST_LIVE_32 : nl >= 8 ? ST_LIVE_8 : ST_LIVE_LT8, 1); }
-#endif
+        )
         const float a = dot3(r.d, r.d);
         if (!TREE) { closest = FLT_MAX; best = -1; }
-#ifdef RT_STATS
+        RT_STATS_ONLY(
         const unsigned long long tC0 = TICK();
         const unsigned long long c4_ = st.cyc[4], c5_ = st.cyc[5], c1_ = st.cyc[1], c3_ = st.cyc[3];
         const bool thin12 = thin && __popcll(__ballot(live)) <= 2;
-#endif
+        )
         if (TREE) closest_tree<COOPG>(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
-#ifdef RT_STATS
+        RT_STATS_ONLY(
         const unsigned long long tC1 = TICK(); st.cyc[0] += tC1 - tC0; st.cyc[2] += tC0; if (thin) dbg_thin_closest += tC1 - tC0;
         if (TREE && thin12) { th[0] += (st.cyc[4] - c4_) - tC0; th[1] += st.cyc[5] - c5_; th[2] += (st.cyc[1] - c1_) - (st.cyc[5] - c5_); th[3] += st.cyc[3] - c3_; }
         if (live) { ++pix_iters; }
-#endif
+        )
         if (live && !(TREE && ts.pending)) {
             ++iters;
             bool done;                                     // this sample's path has ended
@@ -1769,18 +1330,18 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                     { const RenderArgs& C = *cold_args(); r = primary_ray(C.scene.cam, i, j, C.max_x, C.max_y, s); }
                     // classify after every 4th sample while enough of the chain is left for it to matter
                     if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns && iters >= (unsigned int)((COOPG == 2 ? RT_LONG_RATE_DENSE : RT_LONG_RATE) * sample)) {
-#ifdef RT_STATS
+                        RT_STATS_ONLY(
                         if (!is_long) ++dbg_long;
-#endif
+                        )
                         is_long = true;
                     }
                     else if (RT_MED_RATE > 0 && (sample & 7) == 0 && iters >= (unsigned int)(RT_MED_RATE * sample)) is_med = true;
                 } else {
                     WPASS(WP_ENDPIX);
                     end_pixel();
-#ifdef RT_STATS
+                    RT_STATS_ONLY(
                     pix_iters = 0;
-#endif
+                    )
                     STAT(st, ST_SWITCHES, 1);
                     live = false; is_long = false; is_med = false;
                     if (lane < RT_LONG_PER_WAVE && begin_long_pixel()) { /* next long chain */ }
@@ -1790,7 +1351,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         }
     }
 
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     for (int q = 0; q < ST_N; ++q) {
         const bool wave_level = (q == ST_LOOP_ITERS_WAVE || (q >= ST_LIVE_GE56 && q <= ST_LIVE_LT8));
         const bool lane_max = (q == ST_A_ITERS_WAVE || q == ST_B_ROUNDS_WAVE);       // single-wave probes: max over lanes = wave count
@@ -1813,7 +1374,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         atomicAdd(&g_stats[ST_CYC_SCAN], st.cyc[3]); atomicAdd(&g_stats[ST_CYC_SHADE], tot - st.cyc[0]); atomicAdd(&g_stats[ST_SPARE4 + 1], st.cyc[5]); atomicAdd(&g_stats[ST_SPARE4 + 2], st.cyc[6]);
         atomicAdd(&g_stats[ST_REALTIME], __builtin_amdgcn_s_memrealtime() - rK0);
     }
-#endif
+    )
 }
 
 // ---------------------------------------------------------------------------------------------------- scheduling
@@ -1853,12 +1414,12 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     bool live = inside;
     if (live) r = primary_ray(A.scene.cam, i, j, A.max_x, A.max_y, ps);
     int bounces = 0;
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
-#endif
+    )
     float closest = FLT_MAX; int best = -1;
-    TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
+    TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1;
     ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
     while (__ballot(live) != 0ull) {
         const float a = dot3(r.d, r.d);
@@ -1874,9 +1435,9 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     }
     int pix = inside ? bounces : 0;
     for (int off = RT_PILOT_SAMPLES / 2; off > 0; off >>= 1) pix += __shfl_xor(pix, off);       // sum over the pixel's samples
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     if (tile_ok && smp == 0 && local_tile * 16 + sub < (1 << 20)) g_pilot_dbg[local_tile * 16 + sub] = inside ? pix : -1;
-#endif
+    )
     if (pilot && tile_ok && smp == 0) pilot[local_tile * 16 + sub] = (unsigned char)(pix < 255 ? pix : 255);       // per 2x2 block, for k_long_select
     int w = inside ? bounces : 0;
     for (int off = kPerTile / 2; off > 0; off >>= 1) w += __shfl_xor(w, off);         // sum over the tile's 16 pilot pixels x samples
@@ -1979,12 +1540,12 @@ __global__ __launch_bounds__(256) void k_trace(RenderArgs A, const float* rays, 
     if (live) { const float* p = rays + gid * 6; r.o = {p[0], p[1], p[2]}; r.d = {p[3], p[4], p[5]}; }
     const float a = dot3(r.d, r.d);
     float closest = FLT_MAX; int best = -1;
-#ifdef RT_STATS
+    RT_STATS_ONLY(
     Stats st; for (int q = 0; q < ST_N; ++q) st.c[q] = 0;
     for (int q = 0; q < 8; ++q) st.cyc[q] = 0;
-#endif
+    )
     if (TREE) {
-        TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.e = 0; ts.e_end = 0;
+        TreeState ts; ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1;
         ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
         bool act = live;
         do { closest_tree<COOPG>(S, T, s_nodes, r, a, act, closest, best, ts STAT_PASS); act = live && ts.pending; } while (__ballot(act) != 0ull);
@@ -2089,7 +1650,7 @@ hipError_t launch_trace_list(const RenderArgs& A, unsigned blocks, const float* 
 static int render_variant(bool tree, int mode, const DevAccel& acc) {
     (void)mode;
     if (!tree) return 0;
-    if (acc.enabled) return acc.coop_groups >= 4 ? 4 : (RT_DENSE_POOL ? 2 : 1);
+    if (acc.enabled) return acc.coop_groups >= 4 ? 4 : 2;
     return 1;
 }
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
@@ -2120,8 +1681,11 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     // (sparse grids: the pilot paths walk the grid like the render kernel's full waves do, through the wave's pool)
     // flags: 64 bytes per local tile (one per pixel) followed by 16 per local tile (the pilot counts per 2x2 block)
     unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
-    if (tree && render_variant(true, 0, A.tree.acc) == 4 && RT_PILOT_POOL) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
-    else if (tree) hipLaunchKernelGGL((k_tile_cost<true>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
+    // (the pilot paths walk the grid like the render kernel's waves do, through the wave's pool)
+    const int variant = render_variant(tree, 0, A.tree.acc);
+    if (variant == 4) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
+    else if (variant == 2) hipLaunchKernelGGL((k_tile_cost<true, 2>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
+    else if (tree) hipLaunchKernelGGL((k_tile_cost<true, 1>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
     else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
     return launch_select_and_order(A, cost, order, flags, long_list, st, 0);
 }
@@ -2173,16 +1737,7 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
 }
 #endif
 
-#ifdef RT_STATS
-hipError_t read_pilot_dbg(int* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pilot_dbg), sizeof(int) * (size_t)(n < (1 << 20) ? n : (1 << 20))); }
-hipError_t read_wave_dbg(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_dbg), sizeof(unsigned long long) * 8192 * 4); }
-hipError_t read_stats(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * ST_N);
-    if (e != hipSuccess) return e;
-    if (reset) { unsigned long long z[ST_N] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)); }
-    return e;
-}
-#endif
+RT_STATS_READERS
 
 #ifdef RT_TU_CONTRACT
 } // namespace fmac

@@ -11,6 +11,7 @@
 #include <float.h>
 #include "rt_device.h"
 #include "rt_real.h"
+#include "rt_tuning.h"
 
 #pragma clang fp contract(off)
 
@@ -19,24 +20,6 @@ namespace h16 {
 
 #define RT_DEV static __device__ __forceinline__
 typedef half_t R;
-#ifndef RT_H16_LONG_PER_WAVE
-#define RT_H16_LONG_PER_WAVE 16        // pre-classified long chains per thin wave (k_render_h)
-#endif
-#ifndef RT_H16_LONG_RATE
-#define RT_H16_LONG_RATE 14            // a pixel averaging this many bounces per sample (looked at every 4 samples) is a long chain: its wave goes thin; 0 = off
-#endif
-#ifndef RT_H16_LONG_CHECK
-#define RT_H16_LONG_CHECK 4
-#endif
-#ifndef RT_H16_THIN_CAP_DEN
-#define RT_H16_THIN_CAP_DEN 4
-#endif
-#ifndef RT_H16_PILOT_LONG_SUM
-#define RT_H16_PILOT_LONG_SUM 150      // 3x3 pilot sum from which a block's pixels start as long chains (fp32: 200; C4: 200: 57.0 ms, 160: 55.4, 140: 55.1, 120: 55.6, 100: 56.1, 250: 59.7)
-#endif
-#ifndef RT_H16_PILOT_CAP
-#define RT_H16_PILOT_CAP 35            // bounces after which a pilot sample is cut
-#endif
 
 RT_DEV R rf(float f) { return half_t(f); }                 // real_t(float)
 RT_DEV R rd(double d) { return half_t((float)d); }         // real_t(double): double -> float -> half
@@ -174,23 +157,11 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // lane and pass; SMALL ones (fewer than kSmallPairs pairs) would break every span they fall into — a pass cannot cross a segment
 // boundary — so they go to a pool of their own and are tested one segment per lane.  (One pool for both: 1 pair per pass was the
 // fastest setting, 80.0 ms against 96.6 with 4, because most segments were tiny; split: 4 pairs per pass on the big ones.)
-#ifndef RT_H16_BIG
-#define RT_H16_BIG 128
-#endif
-#ifndef RT_H16_SMALL
-#define RT_H16_SMALL 256
-#endif
 constexpr int kBig = RT_H16_BIG;                              // big segments per wave and round (a multiple of 64)
 constexpr int kSmall = RT_H16_SMALL;                          // small segments per wave and round
 constexpr unsigned kSmallPairs = 8u;                          // a node with fewer pairs is a small segment (its count must fit 3 bits)
 constexpr int kCand = 128;                                    // candidate queue of a wave
-#ifndef RT_H16_PP
-#define RT_H16_PP 4                                           // pairs per lane and pass of the big segments' test loop (at most 4: push_pass)
-#endif
 constexpr int kPP = RT_H16_PP;
-#ifndef RT_H16_MINWAVES
-#define RT_H16_MINWAVES 4
-#endif
 #ifdef RT_H16_STATS            // diagnostic build (tools/h16_phases.py): cycles per phase, summed over waves
 #define H16_TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_h16_cyc[8];
@@ -583,10 +554,6 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             }
             static_assert(kBig <= 128, "binary search depth");
             H16_ADD(1, tph);                                         // prefix + search
-#ifdef RT_H16_DOUBLE_TESTS     // diagnostic: the big segments' tests twice (the same keys again: the result does not change)
-            for (int rep = 0; rep < 2; ++rep) {
-            cur = begin; seg_end = begin; { unsigned lo = 0u, hi = n_seg; for (int it = 0; it < 7; ++it) { const unsigned mid = (lo + hi) >> 1; if (hi - lo > 1u) { if (L.pref[mid] <= begin) lo = mid; else hi = mid; } } sg = begin < end ? lo : 0u; }
-#endif
             while (true) {
                 const bool act = cur < end;
                 if (__ballot(act) == 0ull) break;
@@ -619,9 +586,6 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 cur += nb;
                 if (qn >= 64u) drain_candidates(L, lane, qn);
             }
-#ifdef RT_H16_DOUBLE_TESTS
-            }
-#endif
         }
         // ---- phase 2b: the small segments, one per lane (their pairs one after the other: mostly one)
         for (unsigned sb = 0u; sb < n_small; sb += 64u) {

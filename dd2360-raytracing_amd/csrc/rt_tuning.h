@@ -1,0 +1,116 @@
+// rt_tuning.h — every tuning knob of the render kernels in one place, with what was measured when its value was chosen.
+//
+// A knob changes WHEN and BY WHOM work is done, never a pixel: the parity tests pass at any setting.  The values are the measured
+// optima on MI355X for the BASELINE configs (C2/C3: 1200x800x64, N = 500 / 10 000; C4 = C3 in binary16; C5: 3840x2160x256,
+// N = 100 000); "ms" is the render kernel of that config unless said otherwise.  Override with -DRT_<NAME>=value
+// (tools/mkvariant.sh builds such a library, tools/ab.sh times it against the product on one box).  Switches whose other branch
+// lost were removed with their code in round 3 (per-lane walk + cooperative single-ray walk, walk caps, the packed "behind the
+// origin" filter of the binary16 tests, the unchunked progressive hand-out, ...): DESIGN.md §8 keeps what they measured.
+#pragma once
+
+// ---- occupancy -----------------------------------------------------------------------------------------------------------------
+#ifndef RT_RENDER_WAVES
+#define RT_RENDER_WAVES 4       // waves per SIMD k_render is compiled for (512 / 4 = 128 VGPRs).  C3: 3: 22.5 ms, 4: 19.5, 5 (96 VGPRs, spills): 22.2
+#endif
+
+// ---- scheduling: long pixel chains ------------------------------------------------------------------------------
+#ifndef RT_LONG_RATE
+#define RT_LONG_RATE 14         // bounces per sample from which a pixel found in flight makes its wave thin.  C3 (with RT_LONG_CHECK 4): 12: 17.6 ms, 13: 17.17, 14: 16.93, 16: 17.2, 20: 17.55
+#endif
+#ifndef RT_LONG_RATE_DENSE
+#define RT_LONG_RATE_DENSE 20   // the same on dense grids (throughput-bound, not chain-bound).  C5: 14: 668 ms, 20: 663
+#endif
+#ifndef RT_LONG_CHECK
+#define RT_LONG_CHECK 4         // a pixel's rate is looked at every so many samples (a power of two).  C3: 2: 17.9 ms, 4: 16.93, 8: 17.5
+#endif
+#ifndef RT_MED_RATE
+#define RT_MED_RATE 12          // "medium" chains (below RT_LONG_RATE): the wave keeps refilling but issues at priority 1; 0 = off.  C3 (round 1): off 22.88 ms, 10: 22.62, 12: 22.51, 15: 22.53
+#endif
+#ifndef RT_THIN_CAP_DEN
+#define RT_THIN_CAP_DEN 4       // at most 1/4 of the resident waves may go thin for chains found in flight (1/2, 1/8: within +-1 %)
+#endif
+#ifndef RT_LONG_PER_WAVE
+#define RT_LONG_PER_WAVE 16     // pre-classified chains a thin wave starts with.  C3: 2: 20.32 ms, 4: 20.04, 8: 19.84, 16: 19.81, 32: 21.92
+#endif
+// pilot pass (k_tile_cost): RT_PILOT_SAMPLES samples per 2x2 pixel block on a private RNG stream, cut at RT_PILOT_CAP bounces; a block's
+// pixels start as long chains when the pilot bounces of the block and its eight neighbours total >= RT_PILOT_LONG_SUM.  Scored against
+// the chains' true lengths on C3 (profiles/r2/predictor_c3.txt): the block's own count >= 50 finds 22 % of the pixels above 1280
+// iterations; the 3x3 sum >= 200 finds 86 % (13 of the 13 above 2000) and 1 % of what it picks is shorter than 400; >= 160 overruns the 1/64 cap.
+#ifndef RT_PILOT_SAMPLES
+#define RT_PILOT_SAMPLES 2
+#endif
+#ifndef RT_PILOT_LONG_SUM
+#define RT_PILOT_LONG_SUM 200
+#endif
+#ifndef RT_PILOT_CAP
+#define RT_PILOT_CAP 35         // (the pass is as long as its longest sample; 25: C4 +2 ms, 50 = the reference's depth limit)
+#endif
+#ifndef RT_PROG_OWN
+#define RT_PROG_OWN 64          // render_progressive: pixel slots a wave owns before it takes chunks of 64 from the counter.  C3, ms per pass: 0: 0.645, 64: 0.567, 128: 0.611 (one request per lane and pixel: 1.05)
+#endif
+
+// ---- the pooled walks -----------------------------------------------------------------------------------
+#ifndef RT_QUORUM_SPARSE
+#define RT_QUORUM_SPARSE 4      // walk_pool returns when 1/4 of the walkers that entered are left.  C3: off 21.06 ms, 2: 20.14, 3: 19.91, 4: 19.94, 8: 20.41
+#endif
+#ifndef RT_QUORUM_DENSE
+#define RT_QUORUM_DENSE 2       // walk_pool_dense: 1/2 (dense walks are long and uneven).  C5 geometry, round 1: off 134.8 ms, 1/8: 122.1, 1/4: 118.5, 1/2: 114.3
+#endif
+#ifndef RT_QUORUM_MIN
+#define RT_QUORUM_MIN 16        // ... in waves that entered with at least this many walkers
+#endif
+#ifndef RT_POOL_COLS
+#define RT_POOL_COLS 2          // grid columns per ray and round of walk_pool.  C3: 1: 20.95 ms, 2: 20.4, 4: 22.2
+#endif
+#ifndef RT_POOL_COLS_THIN
+#define RT_POOL_COLS_THIN 4     // ... in a wave with few walkers (a thin wave's chains: fewer rounds, fewer dependent round trips).  C2: 14.5 -> 14.1 ms
+#endif
+#ifndef RT_POOL_SPANS
+#define RT_POOL_SPANS 1         // spans a lane steps through side by side in walk_pool (2, 4: within the +-1.5 % run-to-run noise)
+#endif
+#ifndef RT_DENSE_PB
+#define RT_DENSE_PB 4           // entries per lane and pass of walk_pool_dense.  C5: 2: 850 ms, 3: 744, 4: 670, 5: 730, 8: 839
+#endif
+#ifndef RT_DENSE_DRAIN
+#define RT_DENSE_DRAIN 32       // candidates queued before walk_pool_dense resolves them (a found hit starts rejecting sooner; 64: +1 %)
+#endif
+
+// ---- hitable_list scan (the reference traversal of lists) -------------------------------------------------------------------------
+#ifndef RT_LIST_BATCH
+#define RT_LIST_BATCH 8         // spheres per pass of the scalar-load scan (their loads in flight together).  C2 scan: 1: 46.1 ms, 8: 40.2
+#endif
+#ifndef RT_LIST_COOP_COST
+#define RT_LIST_COOP_COST 16    // rays are scanned one at a time with lanes = spheres while live rays x 16 <= list size.  C2 scan: 40.1 -> 36.5 ms
+#endif
+
+// ---- USE_FP16 (rt_kernels_fp16.hip) -----------------------------------------------------------------------------
+#ifndef RT_H16_MINWAVES
+#define RT_H16_MINWAVES 4       // waves per SIMD k_render_h is compiled for (5, 6 with spills: no change)
+#endif
+#ifndef RT_H16_BIG
+#define RT_H16_BIG 128          // big segments (bucket ranges of >= 8 pairs) a wave pools per round (a multiple of 64, at most 128)
+#endif
+#ifndef RT_H16_SMALL
+#define RT_H16_SMALL 256        // small segments per round (C4: the 56 upper cells that hold one large sphere each)
+#endif
+#ifndef RT_H16_PP
+#define RT_H16_PP 4             // pairs per lane and pass of the big segments' test loop (at most 4: push_pass).  C4: 2: 52.7 ms, 3: 48.3, 4: 46.0 (one pool for all segments, round 2: 1: 80.0, 4: 96.6)
+#endif
+#ifndef RT_H16_LONG_PER_WAVE
+#define RT_H16_LONG_PER_WAVE 16 // pre-classified chains per thin wave.  C4 (round 2): 4: 56.7 ms, 8: 57.3, 16: 57.1, 32: 61.5
+#endif
+#ifndef RT_H16_LONG_RATE
+#define RT_H16_LONG_RATE 14     // bounces per sample from which a pixel found in flight makes its wave thin; 0 = off.  C4 (round 2): off 66.3 ms, 10: 57.7, 12: 57.2, 14: 57.1, 16: 57.4
+#endif
+#ifndef RT_H16_LONG_CHECK
+#define RT_H16_LONG_CHECK 4
+#endif
+#ifndef RT_H16_THIN_CAP_DEN
+#define RT_H16_THIN_CAP_DEN 4
+#endif
+#ifndef RT_H16_PILOT_LONG_SUM
+#define RT_H16_PILOT_LONG_SUM 150   // 3x3 pilot sum from which a block's pixels start as long chains (fp32: 200).  C4 (round 2): 100: 56.1 ms, 120: 55.6, 140: 55.1, 160: 55.4, 200: 57.0, 250: 59.7
+#endif
+#ifndef RT_H16_PILOT_CAP
+#define RT_H16_PILOT_CAP 35     // bounces after which a pilot sample is cut (25: +2 ms)
+#endif

@@ -5,40 +5,11 @@ renders on MI355X.  The reference reports SSIM 0.4317 / PSNR 12.4 dB for its fp1
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
-from scipy.ndimage import uniform_filter
 import torch
 import rt_amd as rt
-
-
-def ppm_levels(fb):
-    """int(255.99 * c) per channel as output_to_stream writes it (main.cu:321-333), top row first"""
-    a = np.nan_to_num(np.asarray(fb, np.float64), nan=0.0, posinf=1.0, neginf=0.0)
-    return np.clip((255.99 * a).astype(np.int64), 0, 255)[::-1]
-
-
-def gray8(rgb):
-    # cv2.cvtColor(..., COLOR_RGB2GRAY) on uint8: fixed-point 0.299 / 0.587 / 0.114 with rounding
-    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
-    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.float64)
-
-
-def ssim(x, y, win=7, data_range=255.0):
-    # skimage.metrics.structural_similarity defaults: uniform 7x7 window, sample covariance, K1 = 0.01, K2 = 0.03, borders cropped
-    npx = win * win
-    cov_norm = npx / (npx - 1.0)
-    ux, uy = uniform_filter(x, win), uniform_filter(y, win)
-    uxx, uyy, uxy = uniform_filter(x * x, win), uniform_filter(y * y, win), uniform_filter(x * y, win)
-    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
-    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
-    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
-    pad = (win - 1) // 2
-    return float(s[pad:-pad, pad:-pad].mean())
-
-
-def psnr(x, y):
-    mse = float(((x - y) ** 2).mean())
-    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+from image_metrics import ppm_levels, gray8, ssim, psnr
 
 
 def frame(n, nx, ny, ns, spl, precision):
