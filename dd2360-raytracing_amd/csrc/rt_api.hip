@@ -28,6 +28,9 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc);
 namespace gpubuild { int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int spl, hipStream_t st); }
 const char* render_kernel_name_h(bool tree, int mode);
+#ifdef RT_CC_STATS
+hipError_t read_cc_stats(unsigned long long* out, int reset);
+#endif
 #ifdef RT_H16_STATS
 hipError_t read_h16_stats(unsigned long long* out, int reset);
 #endif
@@ -724,7 +727,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     if (!cap && C.has_done && C.last_stream != st) RT_TRY(hipStreamWaitEvent(st, C.done, 0));
     A.queue = C.d_queue + (size_t)(C.launches++ % kQueueSlots) * kQueueStride;
     C.last_queue = A.queue;
-    RT_TRY(launch_zero_counters(A.queue, 4, st));
+    RT_TRY(launch_zero_counters(A.queue, 6, st));
     if (mode == 1) {
         // render_progressive is one sample per launch (main.cu:119-142, called once per displayed frame, :275).  The pass with
         // current_sample == 1 runs the pilot pass of rt_render and KEEPS the tile order (most expensive tiles first) in the context;
@@ -782,7 +785,9 @@ static int ctx_times(rt_render_ctx& C, float* ms_out, int max, int* count) {
 static int ctx_counters(rt_render_ctx& C, uint32_t* out4) {
     if (!C.last_queue) { out4[0] = out4[1] = out4[2] = out4[3] = 0u; return 0; }
     if (C.has_done) RT_TRY(hipEventSynchronize(C.done));
-    RT_TRY(hipMemcpy(out4, C.last_queue, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t q[6];
+    RT_TRY(hipMemcpy(q, C.last_queue, sizeof(q), hipMemcpyDeviceToHost));
+    out4[0] = q[0]; out4[1] = q[1]; out4[2] = q[2] + q[4]; out4[3] = q[3] + q[5];      // (chains started alone in a wave are listed apart: [4], [5])
     return 0;
 }
 int rt_world_render_counters(rt_world* W, uint32_t* out4) {
@@ -853,6 +858,9 @@ int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float*
     return (int)launch_trace(world->z->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
 
+#ifdef RT_CC_STATS
+int rt_debug_cc(unsigned long long* out4, int reset) { return (int)rt::read_cc_stats(out4, reset); }      // diagnostic variant only
+#endif
 #ifdef RT_H16_STATS
 int rt_debug_h16(unsigned long long* out8, int reset) { return (int)rt::read_h16_stats(out8, reset); }      // diagnostic variant only
 #endif

@@ -972,7 +972,7 @@ static size_t h16_lds_bytes(bool tree, const DevTree& T) {
     return tree ? (size_t)T.n_nodes * (T.h16_np[0] > 0 ? (regular ? 2 : 1) * sizeof(float4) : sizeof(DevNode)) + 4 * sizeof(h16::WaveLds) : 0;
 }
 
-hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum);   // rt_kernels.hip
+hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum, int solo_sum);   // rt_kernels.hip
 
 // the scheduling pre-pass of a binary16 render: pilot pass in binary16, then the precision-independent selection and ordering
 hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
@@ -982,7 +982,7 @@ hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsign
     unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
     if (tree) hipLaunchKernelGGL((h16::k_tile_cost_h<true>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
     else hipLaunchKernelGGL((h16::k_tile_cost_h<false>), dim3(blocks), dim3(256), lds, st, A, cost, pilot);
-    return launch_select_and_order(A, cost, order, flags, long_list, st, RT_H16_PILOT_LONG_SUM);
+    return launch_select_and_order(A, cost, order, flags, long_list, st, RT_H16_PILOT_LONG_SUM, 0x7fffffff);
 }
 
 hipError_t launch_render_h(const RenderArgs& A, bool tree, int mode, hipStream_t st) {
