@@ -1,0 +1,13 @@
+import ctypes as C, os, sys
+sys.path.insert(0, "/root/repo/dd2360-raytracing_amd")
+import torch, rt_amd as rt
+nx, ny, ns, n, spl = 1200, 800, 16, 10000, 32
+W = rt.World(n, nx, ny, precision=rt.FP16); O = rt.Octree(W, spl)
+st = rt.alloc_rand_state(nx, ny); fb = rt.alloc_fb(nx, ny, precision=rt.FP16)
+L = rt.lib(); out = (C.c_ulonglong * 8)()
+for k in range(2):
+    rt.render_init(nx, ny, st); rt.render(fb, nx, ny, ns, W, st, O); torch.cuda.synchronize()
+    L.rt_debug_h16(out, 1)
+v = list(out)
+samples = nx * ny * ns
+print("per sample: candidates evaluated %.2f, past the float filter (exact roots) %.2f (%.1f %%)" % (v[5] / samples, v[6] / samples, 100.0 * v[6] / max(1, v[5])))
