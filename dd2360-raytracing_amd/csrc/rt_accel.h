@@ -232,9 +232,10 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     // rays side by side in the cooperative walk pay off while a chunk of 8 columns is a handful of entries (C3: 3.6 per cell);
     // on dense grids (C5: N = 100 000, ~40 per cell) an uneven pair of rays costs twice the longer one
     p.coop_groups = (double)total <= 8.0 * (double)ncell ? 4 : 1;
-    // the chain cache pays where a 3 x 3 block of cells holds a handful of spheres and the frame waits for its chains with the
-    // chip half idle (C2: 13.6 -> 11.6 ms); at C3's 3.6 entries per cell it costs 0.5 ms (profiles/r3/chain_cache_ab.txt)
-    p.chain_cache = (double)total <= RT_CHAIN_CACHE_DENSITY * (double)ncell ? 1 : 0;
+    // very sparse grids (lists of a few hundred spheres): the frame waits for its pixel chains with the chip half idle, so every
+    // pre-classified chain starts ALONE in a wave (C2: 13.4 -> 11.6 ms); at C3's 3.6 entries per cell the waves set aside cost
+    // more throughput than the chains gain (profiles/r3/chain_cache_ab.txt)
+    p.solo_chains = (double)total <= RT_SOLO_DENSITY * (double)ncell ? 1 : 0;
 }
 
 } // namespace rt

@@ -28,9 +28,6 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc);
 namespace gpubuild { int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int spl, hipStream_t st); }
 const char* render_kernel_name_h(bool tree, int mode);
-#ifdef RT_CC_STATS
-hipError_t read_cc_stats(unsigned long long* out, int reset);
-#endif
 #ifdef RT_H16_STATS
 hipError_t read_h16_stats(unsigned long long* out, int reset);
 #endif
@@ -858,9 +855,6 @@ int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float*
     return (int)launch_trace(world->z->dev, T, d_octree != nullptr, d_rays, n, d_out, (hipStream_t)stream);
 }
 
-#ifdef RT_CC_STATS
-int rt_debug_cc(unsigned long long* out4, int reset) { return (int)rt::read_cc_stats(out4, reset); }      // diagnostic variant only
-#endif
 #ifdef RT_H16_STATS
 int rt_debug_h16(unsigned long long* out8, int reset) { return (int)rt::read_h16_stats(out8, reset); }      // diagnostic variant only
 #endif

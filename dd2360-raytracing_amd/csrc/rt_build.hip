@@ -663,7 +663,7 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     p.zone2 = (float)(kZone * kZone);
     p.enabled = 1;
     p.coop_groups = (double)total <= 8.0 * (double)ncell ? 4 : 1;
-    p.chain_cache = (double)total <= RT_CHAIN_CACHE_DENSITY * (double)ncell ? 1 : 0;
+    p.solo_chains = (double)total <= RT_SOLO_DENSITY * (double)ncell ? 1 : 0;
     AH.p = p; AH.n_entries = total;
     Z.dev.acc = p;
     Z.uploaded = true;

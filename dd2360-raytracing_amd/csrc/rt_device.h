@@ -71,8 +71,8 @@ struct DevAccel {
     float zone2;               // fast path only for ray origins with |o - (0,1,0)|^2 <= zone2
     int32_t enabled;
     int32_t coop_groups;       // cooperative walk: up to this many rays side by side (4 on sparse grids, 1 on dense ones)
-    int32_t chain_cache;       // very sparse grids (at most one entry per cell on average: lists of a few hundred spheres): a wave's only ray is
-                               // served from the chain cache, and the longest chains start alone in their waves (rt_kernels.hip)
+    int32_t solo_chains;       // very sparse grids (at most one entry per cell on average: lists of a few hundred spheres): the pre-classified
+                               // long chains start alone in their waves (k_render<true,*,5>)
 };
 
 struct DevTree {

@@ -852,176 +852,19 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
 // A pooled walk returns once most of the wave's rays are done (quorum): a lane whose walk is not finished comes back with
 // ts.pending set and resumes on the next call with the same ray, while the lanes that are done go on to shade and start new
 // rays — the wave does not wait for its longest walk.  `closest`/`best` persist with the caller.
-// COOPG selects the walk: 4 = walk_pool (sparse grids), 5 = the same with the chain cache (very sparse grids), 2 = walk_pool_dense, 1 = none — trees without a candidate grid (and the
+// COOPG selects the walk: 4 = walk_pool (sparse grids), 5 = the same walk, the pre-classified chains start alone in their waves (very sparse grids), 2 = walk_pool_dense, 1 = none — trees without a candidate grid (and the
 // reference traversal mode) take the literal scan for every ray.
-struct TreeState { Walk W; float g_t; int g_id; bool tie, pending;
-                   int cc_a, cc_b, cc_slot, cc_skip; bool chainy; };        // the chain cache (below): descriptor (-1: none), slot of the hit to shade, build back-off, the lane's pixel is a long chain
+struct TreeState { Walk W; float g_t; int g_id; bool tie, pending; };
 RT_DEV void tree_state_init(TreeState& ts) {
     ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1;
     ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
-    ts.cc_a = -1; ts.cc_b = 0; ts.cc_slot = -1; ts.cc_skip = 0; ts.chainy = false;
 }
-
-// ---------------------------------------------------------------------------------------------------- the chain cache
-// A frame is as long as its longest pixel chain: 2 500 bounces of ONE ray at a time, each through ground test, large
-// spheres, walk set-up, a pooled-walk round (three dependent L2 round trips, six LDS round trips) and a shade that waits for the hit
-// sphere's record — ~17 k cycles of latency that nothing hides in a wave with one live lane.  Those chains live in crevices: dozens
-// of bounces between one or two small spheres and the ground, inside one or two grid cells.  A wave whose ONLY live ray is such a
-// chain keeps the neighbourhood in its LDS (the area of its walk pool): the ground, the large spheres, and every entry of the 3 x 3
-// grid cells around the ray's origin — centre, r^2, brick, shading record.  A bounce is then: all cached spheres tested at once,
-// one per lane, with the reference's exact roots; brick eligibility; a DPP minimum; no memory round trip.  It is taken only when
-// it provably gives the walk's answer:
-//   * the candidate set is a superset of the walk's: the columns the walk would read, clipped by the hit that was found exactly as
-//     walk_pool clips (walk_setup / walk_clip, the same column ranges), must lie inside the cached block — a sphere outside those
-//     columns cannot offer a smaller t (App. A.2), and everything inside them was tested;
-//   * every candidate that could win (t <= the best) must have its eligibility proven by its brick (App. A.3); one that would need
-//     the slab test, an exact tie between two tree spheres, a ray outside the preconditions of the fast path: the normal path runs
-//     (and leaves the cache invalid: it uses the same LDS).
-// The ground wins its ties as in hitTree (it is tested first, candidates need a strictly smaller t).
-#ifndef RT_CHAIN_CACHE
-#define RT_CHAIN_CACHE 1
-#endif
-#ifdef RT_CC_STATS             // diagnostic variant: [0] blocks fetched [1] bounces served [2] bounces refused [3] bounces of a wave's only ray
-__device__ unsigned long long g_cc[4];
-#define CC_STAT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_cc[k], 1ull); } while (0)
-#else
-#define CC_STAT(k) ((void)0)
-#endif
-constexpr int kCCMax = 56;
-struct ChainCache { float4 hot[kCCMax], blo[kCCMax], bhi[kCCMax], geom[kCCMax], mat[kCCMax]; int kind[kCCMax]; };
-static_assert(sizeof(ChainCache) <= sizeof(WalkLds), "the chain cache lives in the wave's walk pool");
-
-// the neighbourhood of ray origin (ox, oz) into the wave's LDS; returns the descriptor pair (a < 0: no cache)
-RT_DEV void chain_build(const DevScene& S, const DevTree& T, ChainCache& CC, float ox, float oz, int& cc_a, int& cc_b) {
-    const DevAccel& A = T.acc;
-    const int lane = threadIdx.x & 63;
-    const int G = A.G;
-    cc_a = -1; cc_b = 0;
-    const float fx = (ox - A.g0) * A.inv_h, fz = (oz - A.g0) * A.inv_h;
-    if (!(fx >= 0.0f && fx < (float)G && fz >= 0.0f && fz < (float)G) || A.n_large > 8) return;
-    const int cx = (int)fx, cz = (int)fz;
-    const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, G - 1), bz0 = max(cz - 1, 0), bz1 = min(cz + 1, G - 1);
-    int e0 = 0, cnt = 0;                                        // lanes 0..2: the entry range of a column of the block (x-major copy: cells of a column are contiguous)
-    if (lane <= bx1 - bx0) { const int cb = (bx0 + lane) * G; e0 = A.cs[cb + bz0]; cnt = A.cs[cb + bz1 + 1] - e0; }
-    const int c0 = bcast(cnt, 0), c1 = bcast(cnt, 1), c2 = bcast(cnt, 2), f0 = bcast(e0, 0), f1 = bcast(e0, 1), f2 = bcast(e0, 2);
-    const int gv = S.ground_valid ? 1 : 0, n_fixed = gv + A.n_large;
-    const int total = n_fixed + c0 + c1 + c2;                   // one lane per registration; a sphere is registered in every cell it touches
-    if (total > 64) return;
-    float4 hot = make_float4(0.f, 0.f, 0.f, 0.f), blo = hot, bhi = hot; int id = -1;
-    if (lane < total) {
-        if (gv && lane == 0) { hot = S.list_hot[0]; id = 0; }
-        else if (lane < n_fixed) { const int k = lane - gv; hot = A.large_hot[k]; blo = A.large_brick[2 * k]; bhi = A.large_brick[2 * k + 1]; id = __float_as_int(blo.w); }
-        else {
-            const int j = lane - n_fixed;
-            const int e = j < c0 ? f0 + j : (j < c0 + c1 ? f1 + (j - c0) : f2 + (j - c0 - c1));
-            hot = A.hot[e]; blo = A.brick[2 * e]; bhi = A.brick[2 * e + 1]; id = __float_as_int(blo.w);
-        }
-    }
-    bool keep = lane < total;                                   // the first registration of every sphere (C3: ~50 registrations, ~22 spheres a block)
-    for (int i = n_fixed; i < total - 1; ++i) { const int idi = bcast(id, i); if (lane > i && id == idi) keep = false; }
-    const unsigned long long mk = __ballot(keep);
-    const int nkeep = __popcll(mk);
-    if (nkeep > kCCMax) return;
-    if (keep) {
-        const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-        CC.hot[slot] = hot; CC.blo[slot] = blo; CC.bhi[slot] = bhi;
-        CC.geom[slot] = S.shade[2 * id]; CC.mat[slot] = S.shade[2 * id + 1]; CC.kind[slot] = S.kind8[id];
-    }
-    cc_a = nkeep | (bx0 << 8) | (bx1 << 20);
-    cc_b = bz0 | (bz1 << 12);
-    walk_sync();
-}
-
-// one bounce of the wave's only ray q from the cache; true: t / id / slot are the walk's answer (id -1: nothing hit)
-RT_DEV bool chain_resolve(const DevScene& S, const DevTree& T, const ChainCache& CC, const RayF& q, float qa, int cc_a, int cc_b, float& t_out, int& id_out, int& slot_out) {
-    const DevAccel& A = T.acc;
-    const int lane = threadIdx.x & 63;
-    const int n = cc_a & 255, gv = S.ground_valid ? 1 : 0;
-    const float inf = __builtin_inff();
-    float cand = inf; bool elig = false; int id = -1;
-    if (lane < n) {
-        cand = sphere_candidate(q, qa, CC.hot[lane]);           // sphere.h:18-43: what this sphere offers
-        if (gv && lane == 0) { id = 0; elig = cand < inf; }
-        else if (cand < inf) { const float4 blo = CC.blo[lane], bhi = CC.bhi[lane]; id = __float_as_int(blo.w); elig = in_brick(q, cand, blo, bhi); }
-    }
-    const float mn = group_min<64>(elig ? cand : inf);
-    if (__ballot(lane < n && !elig && cand < inf && cand <= mn) != 0ull) return false;      // could win, eligibility not proven by its brick
-    id_out = -1; slot_out = -1; t_out = FLT_MAX;
-    if (mn < inf) {
-        const unsigned long long mm = __ballot(elig && cand == mn);
-        if (gv && (mm & 1ull)) { id_out = 0; slot_out = 0; }
-        else {
-            const int first = __ffsll((long long)mm) - 1;
-            const int wid = bcast(id, first);
-            if (__ballot(elig && cand == mn && id != wid) != 0ull) return false;            // two tree spheres at the same t: the visit order decides
-            id_out = wid; slot_out = first;
-        }
-        t_out = mn;
-    }
-    // the columns the walk would read for this result: inside the cached block?
-    const Walk W = walk_setup(A, q, t_out, id_out);
-    if (W.walking) {
-        const int ncol = W.fwd ? W.iend - W.i : W.i - W.iend;
-        if (ncol > 3) return false;
-        const bool xmajor = W.coff == 0;
-        const int bx0 = (cc_a >> 8) & 0xfff, bx1 = (cc_a >> 20) & 0xfff, bz0 = cc_b & 0xfff, bz1 = (cc_b >> 12) & 0xfff;
-        const int bm0 = xmajor ? bx0 : bz0, bm1 = xmajor ? bx1 : bz1, bn0 = xmajor ? bz0 : bx0, bn1 = xmajor ? bz1 : bx1;
-        const float fG = (float)A.G, fGm = fG - 0.5f, s_c = 2e-3f * A.inv_h;
-        for (int c = 0; c < ncol; ++c) {
-            const int col = W.i + (W.fwd ? c : -c);
-            if (col < bm0 || col > bm1) return false;
-            const float u0 = W.on_c + ((float)col - W.om_c) * W.slope, u1 = u0 + W.slope;       // the cells of the column, as walk_pool finds them
-            const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-            if (hi >= 0.0f && lo < fG) {
-                const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGm);
-                if (k0 < bn0 || k1 > bn1) return false;
-            }
-        }
-    }
-    return true;
-}
-
 
 template <int COOPG>
 RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, const RayF& r, float a, bool live, float& closest, int& best, TreeState& ts STAT_ARG) {
     const bool fresh = live && !ts.pending;
     STAT(st, ST_RAYS, fresh ? 1 : 0);
     if (fresh) { closest = FLT_MAX; best = -1; }
-    if (COOPG == 5 && RT_CHAIN_CACHE && T.acc.enabled) {
-        // the wave's only live ray, from the chain cache (above)
-        const unsigned long long ml = __ballot(live);
-        if (__popcll(ml) == 1 && __ballot(fresh) == ml) {
-            const int Lc = __ffsll((long long)ml) - 1;
-            RayF q;
-            q.o.x = bcast(r.o.x, Lc); q.o.y = bcast(r.o.y, Lc); q.o.z = bcast(r.o.z, Lc);
-            q.d.x = bcast(r.d.x, Lc); q.d.y = bcast(r.d.y, Lc); q.d.z = bcast(r.d.z, Lc);
-            const float qa = bcast(a, Lc);
-            const float zx = q.o.x, zy = q.o.y - 1.0f, zz = q.o.z;
-            const bool fastq = (qa >= 9.094947e-13f) && (qa <= 1.0995116e12f) && (q.d.x != 0.0f) && (q.d.z != 0.0f)
-                               && (fabsf(q.d.y) >= 9.094947e-13f) && (zx * zx + zy * zy + zz * zz <= T.acc.zone2);
-            if (fastq) {
-                ChainCache& CC = *(ChainCache*)((WalkLds*)(s_nodes + T.n_nodes * 3) + (threadIdx.x >> 6));      // (this wave's pool area, WalkLds-sized)
-                bool built = false;
-                if (ts.cc_a >= 0) CC_STAT(3);
-                // (a block is fetched for pixels known to be long chains only: an ordinary ray rarely stays inside one)
-                if (ts.cc_a < 0 && ts.cc_skip == 0 && __ballot(live && ts.chainy) != 0ull) { chain_build(S, T, CC, q.o.x, q.o.z, ts.cc_a, ts.cc_b); built = true; CC_STAT(0); }
-                if (ts.cc_a >= 0) {
-                    float ct; int cid, cslot;
-                    if (chain_resolve(S, T, CC, q, qa, ts.cc_a, ts.cc_b, ct, cid, cslot)) {
-                        CC_STAT(1);
-                        if (live) { closest = ct; best = cid; }
-                        ts.cc_slot = cslot; ts.pending = false; ts.tie = false; ts.W.walking = false;
-                        return;
-                    }
-                    CC_STAT(2);
-                    ts.cc_a = -1;                                    // the ray left the block (or needs the slab test): the normal path, a new block later
-                    if (built) ts.cc_skip = 4;                       // ... not at once if a fresh block did not even serve its first ray
-                } else if (built) ts.cc_skip = 8;                    // (no block here: too many spheres, or off the grid)
-            }
-        }
-        if (ts.cc_skip > 0 && __ballot(fresh) != 0ull) --ts.cc_skip;
-        ts.cc_a = -1; ts.cc_slot = -1;                               // (the walk below uses the cache's LDS)
-    }
     if (S.ground_valid && fresh) {
         WPASS(WP_GROUND);
         const float4 g = S.list_hot[0];
@@ -1138,8 +981,10 @@ RT_DEV RayF primary_ray(const rt_camera& c, int i, int j, int max_x, int max_y, 
 }
 
 // material::scatter for the sphere that was hit.  Returns false when the path is absorbed (metal, material.h:72).
-// (g, m, kind: the hit sphere's shading record — geometry (c, r), material, tag)
-RT_DEV bool scatter_rec(const float4 g, const float4 m, const int kind, float t, RayF& r, V3& att, Rng& s) {
+RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rng& s) {
+    const float4 g = S.shade[2 * sphere];
+    const float4 m = S.shade[2 * sphere + 1];
+    const int kind = S.kind8[sphere];
     V3 p, n;
     p.x = r.o.x + t * r.d.x; p.y = r.o.y + t * r.d.y; p.z = r.o.z + t * r.d.z;            // ray.h:13
     n.x = (p.x - g.x) / g.w; n.y = (p.y - g.y) / g.w; n.z = (p.z - g.z) / g.w;            // sphere.h:29
@@ -1202,10 +1047,6 @@ RT_DEV bool scatter_rec(const float4 g, const float4 m, const int kind, float t,
     if (rng_uniform(s) < reflect_prob) { r.d.x = rx; r.d.y = ry; r.d.z = rz; }
     else { r.d.x = fx; r.d.y = fy; r.d.z = fz; }
     return true;
-}
-
-RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rng& s) {
-    return scatter_rec(S.shade[2 * sphere], S.shade[2 * sphere + 1], (int)S.kind8[sphere], t, r, att, s);
 }
 
 // background gradient of color() — main.cu:67-72
@@ -1350,7 +1191,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         }
     };
     // take the next pre-classified long chain, if any is left (lanes 0..RT_LONG_PER_WAVE-1 only)
-    // (from_solo: the list of the longest chains, one per wave: a wave whose only ray is a crevice chain serves it from the chain cache)
+    // (from_solo: the list of the chains that start one per wave, k_render<true,*,5>)
     auto begin_long_pixel = [&](bool from_solo) -> bool {
         if (!use_long || (from_solo ? solo_done : long_done)) return false;
         const RenderArgs& A = *cold_args();
@@ -1412,7 +1253,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     unsigned long long dbg_thin_cyc = 0, dbg_thin_closest = 0, dbg_thin1_cyc = 0; unsigned int dbg_thin1_iters = 0; unsigned long long dbg_t_prev = TICK();
     )
     // start: pre-classified long chains first, RT_LONG_PER_WAVE per wave, in waves that are thin from the beginning
-    constexpr bool kSolo = TREE && COOPG == 5 && RT_CHAIN_CACHE;       // (the longest chains alone in their waves: the variant with the chain cache)
+    constexpr bool kSolo = TREE && COOPG == 5;       // (the pre-classified chains alone in their waves: very sparse grids)
     if (kSolo && lane == 0 && begin_long_pixel(true)) solo = true;
     if (__ballot(live) == 0ull && lane < RT_LONG_PER_WAVE) begin_long_pixel(false);
     if (__ballot(live) != 0ull) { thin = true; __builtin_amdgcn_s_setprio(3); }
@@ -1478,11 +1319,6 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         const unsigned long long c4_ = st.cyc[4], c5_ = st.cyc[5], c1_ = st.cyc[1], c3_ = st.cyc[3];
         const bool thin12 = thin && __popcll(__ballot(live)) <= 2;
         )
-#ifdef RT_CC_NEVER
-        ts.chainy = false;
-#else
-        ts.chainy = is_long;
-#endif
         if (TREE) closest_tree<COOPG>(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
         RT_STATS_ONLY(
@@ -1494,11 +1330,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             ++iters;
             bool done;                                     // this sample's path has ended
             if (best >= 0) {
-                bool cont;
-                if (TREE && COOPG == 5 && RT_CHAIN_CACHE && ts.cc_slot >= 0) {          // the hit came from the chain cache: so does its shading record
-                    const ChainCache& CC = *(const ChainCache*)((const WalkLds*)(s_nodes + cold_args()->tree.n_nodes * 3) + (threadIdx.x >> 6));
-                    cont = scatter_rec(CC.geom[ts.cc_slot], CC.mat[ts.cc_slot], CC.kind[ts.cc_slot], closest, r, att, s);
-                } else cont = scatter(cold_args()->scene, best, closest, r, att, s);
+                const bool cont = scatter(cold_args()->scene, best, closest, r, att, s);
                 ++depth;
                 done = !cont || depth >= 50;               // absorbed, or 50 bounces used up: contributes (0,0,0)
             } else {
@@ -1835,7 +1667,7 @@ hipError_t launch_trace_list(const RenderArgs& A, unsigned blocks, const float* 
 static int render_variant(bool tree, int mode, const DevAccel& acc) {
     (void)mode;
     if (!tree) return 0;
-    if (acc.enabled) return acc.coop_groups >= 4 ? ((RT_CHAIN_CACHE && acc.chain_cache) ? 5 : 4) : 2;
+    if (acc.enabled) return acc.coop_groups >= 4 ? (acc.solo_chains ? 5 : 4) : 2;
     return 1;
 }
 const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
@@ -1874,7 +1706,7 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     else if (variant == 2) hipLaunchKernelGGL((k_tile_cost<true, 2>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
     else if (tree) hipLaunchKernelGGL((k_tile_cost<true, 1>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
     else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
-    // (chains in waves of their own: sparse grids only — they are what the chain cache serves)
+    // (chains in waves of their own: the variant for very sparse grids)
     return launch_select_and_order(A, cost, order, flags, long_list, st, 0, variant == 5 ? RT_PILOT_SOLO_SUM : 0x7fffffff);
 }
 
@@ -1928,13 +1760,6 @@ hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y
 #endif
 
 RT_STATS_READERS
-#if defined(RT_CC_STATS) && !defined(RT_TU_LIST) && !defined(RT_TU_CONTRACT)
-hipError_t read_cc_stats(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cc), sizeof(unsigned long long) * 4);
-    if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_cc), z, sizeof(z)); }
-    return e;
-}
-#endif
 
 #ifdef RT_TU_CONTRACT
 } // namespace fmac

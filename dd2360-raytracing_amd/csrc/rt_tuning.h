@@ -42,11 +42,11 @@
 #ifndef RT_PILOT_LONG_SUM
 #define RT_PILOT_LONG_SUM 200
 #endif
-#ifndef RT_CHAIN_CACHE_DENSITY
-#define RT_CHAIN_CACHE_DENSITY 1.0   // grids with at most this many entries per cell use the chain cache (DevAccel::chain_cache).  C2 (0.2 per cell): 13.6 -> 11.6 ms; C3 (3.6): 17.1 -> 17.7
+#ifndef RT_SOLO_DENSITY
+#define RT_SOLO_DENSITY 1.0     // grids with at most this many entries per cell start their chains solo (DevAccel::solo_chains, k_render<true,*,5>).  C2 (0.2 per cell): 13.4 -> 11.6 ms; C3 (3.6): 17.25 -> 17.4-17.5
 #endif
 #ifndef RT_PILOT_SOLO_SUM
-#define RT_PILOT_SOLO_SUM 200   // 3x3 pilot sum from which a chain starts ALONE in a wave (k_render<true,*,5>: the chain cache serves a wave's only ray).  C2: none 13.41 ms, 300: 11.80, 250: 11.58, 200: 11.51, 150 (with RT_PILOT_LONG_SUM 150): 12.18
+#define RT_PILOT_SOLO_SUM 200   // 3x3 pilot sum from which a chain starts ALONE in a wave (k_render<true,*,5>).  C2: none 13.41 ms, 300: 11.80, 250: 11.58, 200: 11.51, 150 (with RT_PILOT_LONG_SUM 150): 12.18
 #endif
 #ifndef RT_PILOT_CAP
 #define RT_PILOT_CAP 35         // (the pass is as long as its longest sample; 25: C4 +2 ms, 50 = the reference's depth limit)
