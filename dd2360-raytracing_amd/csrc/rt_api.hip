@@ -294,7 +294,7 @@ int rt_render_ctx_reserve(rt_render_ctx* C, int max_x, int max_y, rt_partition p
     if (!C || max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
     const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
     const int rc = ctx_prepare(*C);
-    return rc ? rc : ctx_reserve(*C, (tiles - part.part + part.nparts - 1) / part.nparts);
+    return rc ? rc : ctx_reserve(*C, part_local_tiles(tiles, part.part, part.nparts));
 }
 int rt_render_ctx_destroy(rt_render_ctx* C) {
     if (!C) return 0;
@@ -656,7 +656,7 @@ int64_t rt_part_pixels(int max_x, int max_y, rt_partition part) {
     if (max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
     if (part.nparts == 1) return (int64_t)max_x * max_y;
     const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
-    return (tiles - part.part + part.nparts - 1) / part.nparts * 64;
+    return part_local_tiles(tiles, part.part, part.nparts) * 64;
 }
 
 int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partition part, void* stream) {
@@ -708,7 +708,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     A.tiles_x = (max_x + 7) / 8; A.tiles_y = (max_y + 7) / 8;
     A.part = part.part; A.nparts = part.nparts;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
-    A.n_local_tiles = (tiles - part.part + part.nparts - 1) / part.nparts;
+    A.n_local_tiles = part_local_tiles(tiles, part.part, part.nparts);
     A.scene = world->z->dev;
     A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;

@@ -15,6 +15,28 @@ constexpr float kRootHalfXZf = (float)kRootHalfXZ, kInvCellXZf = 1.0f / 2.75f, k
 static_assert(kCellXZ == 2.75 && 1.0 / kCellY == 4.0, "level-3 cells of the reference's root box");
 
 
+// The tile split of a frame over parts (rt_amd.h, rt_partition): runs of RT_PART_RUN consecutive tiles dealt round-robin.
+// Every kernel and the host go through these three functions — nothing else knows the mapping.
+#ifndef RT_PART_RUN_BUILD
+#define RT_PART_RUN_BUILD RT_PART_RUN           // (tools/mkvariant.sh -DRT_PART_RUN_BUILD=n: A/B of the run length)
+#endif
+constexpr long long kPartRun = RT_PART_RUN_BUILD;
+__host__ __device__ inline long long part_tile(long long local_tile, int part, int nparts) {          // global tile of a part's local tile
+    if (nparts == 1) return local_tile;
+    return ((local_tile / kPartRun) * nparts + part) * kPartRun + local_tile % kPartRun;
+}
+__host__ __device__ inline long long part_local_tiles(long long tiles, int part, int nparts) {        // tiles of the frame that belong to `part`
+    const long long round = (long long)nparts * kPartRun;
+    long long extra = tiles % round - (long long)part * kPartRun;
+    extra = extra < 0 ? 0 : (extra > kPartRun ? kPartRun : extra);
+    return tiles / round * kPartRun + extra;
+}
+__host__ __device__ inline void part_owner(long long tile, int nparts, int& part, long long& local_tile) {   // inverse of part_tile
+    const long long run = tile / kPartRun;
+    part = (int)(run % nparts);
+    local_tile = (run / nparts) * kPartRun + tile % kPartRun;
+}
+
 // One node of the traversal copy of the Octree, in depth-first pre-order (children in index order, the visit
 // order of traverseTree, acceleration_structure.h:276-304).  48 bytes = 3 x 16 B so a lane fetches it with
 // three ds_read_b128 from LDS.

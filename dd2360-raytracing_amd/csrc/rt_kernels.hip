@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
     const int lane = threadIdx.x & 63;
     const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (local_tile >= n_local_tiles) return;
-    const long long tile = part + local_tile * nparts;
+    const long long tile = part_tile(local_tile, part, nparts);
     const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
     const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
     const bool inside = (i < max_x) && (j < max_y);
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             const long long rank = blk * 64 + within % tiles_in_blk;          // position in the hand-out order
             const int l = (int)(within / tiles_in_blk);
             const long long local_tile = A.order ? (long long)A.order[rank] : rank;
-            const long long tile = A.part + local_tile * A.nparts;
+            const long long tile = part_tile(local_tile, A.part, A.nparts);
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
             const bool taken = use_long && A.long_flag[local_tile * 64 + l];      // long chains are handed out separately
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         }
         const long long local_tile = pid >> 6;
         const int l = (int)(pid & 63);
-        const long long tile = A.part + local_tile * A.nparts;
+        const long long tile = part_tile(local_tile, A.part, A.nparts);
         const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
         i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
         idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             fb[0] = sqrtf(col.x); fb[1] = sqrtf(col.y); fb[2] = sqrtf(col.z);
             RT_STATS_ONLY(
             // diagnostic build: chain length and end / start time (100 MHz ticks mod 2^24) instead of colour
-            fb[0] = (float)pix_iters; fb[1] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffffull); fb[2] = (float)(pix_t0 & 0xffffffull);
+            fb[0] = (float)pix_iters; fb[1] = (float)((__builtin_amdgcn_s_memrealtime() >> 4) & 0xffffffull); fb[2] = (float)((pix_t0 >> 4) & 0xffffffull);
             )
         } else {
             if (A.ns == 1) { fb[0] = col.x; fb[1] = col.y; fb[2] = col.z; }
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     static_assert(RT_PILOT_SAMPLES == 1 || RT_PILOT_SAMPLES == 2 || RT_PILOT_SAMPLES == 4, "pilot samples per pixel");
     const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kTilesPerWave + lane / kPerTile;
     const bool tile_ok = local_tile < A.n_local_tiles;
-    const long long tile = A.part + (tile_ok ? local_tile : 0) * A.nparts;
+    const long long tile = part_tile(tile_ok ? local_tile : 0, A.part, A.nparts);
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int sub = (lane % kPerTile) / RT_PILOT_SAMPLES, smp = lane % RT_PILOT_SAMPLES;
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
@@ -1469,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
     if (g >= A.n_local_tiles * 16) return;
     const long long local_tile = g >> 4;
     const int sub = (int)(g & 15);
-    const long long tile = A.part + local_tile * A.nparts;
+    const long long tile = part_tile(local_tile, A.part, A.nparts);
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int bx = tx * 4 + (sub & 3), by = ty * 4 + (sub >> 2);
     const int own = pilot[g];
@@ -1481,8 +1481,9 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
             const int nx_ = bx + dx, ny_ = by + dy;
             int v = own;
             if (nx_ >= 0 && ny_ >= 0 && nx_ < A.tiles_x * 4 && ny_ < A.tiles_y * 4) {
-                const long long nt = (long long)(ny_ >> 2) * A.tiles_x + (nx_ >> 2) - A.part;
-                if (nt >= 0 && nt % A.nparts == 0) v = pilot[(nt / A.nparts) * 16 + (ny_ & 3) * 4 + (nx_ & 3)];
+                int owner; long long nl;
+                part_owner((long long)(ny_ >> 2) * A.tiles_x + (nx_ >> 2), A.nparts, owner, nl);
+                if (owner == A.part) v = pilot[nl * 16 + (ny_ & 3) * 4 + (nx_ & 3)];
             }
             sum += v;
         }
@@ -1588,7 +1589,9 @@ __global__ __launch_bounds__(256) void k_assemble(float* full, const float* part
     const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
     const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
     if (i >= max_x || j >= max_y) return;
-    const long long src = (tile % nparts) * part_stride_px + (tile / nparts) * 64 + lane;
+    int owner; long long local_tile;
+    part_owner(tile, nparts, owner, local_tile);
+    const long long src = owner * part_stride_px + local_tile * 64 + lane;
     const long long dst = (long long)j * max_x + i;
     full[dst * 3 + 0] = parts[src * 3 + 0]; full[dst * 3 + 1] = parts[src * 3 + 1]; full[dst * 3 + 2] = parts[src * 3 + 2];
 }
@@ -1607,7 +1610,7 @@ hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st) {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st) {
     const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
     const long long tiles = (long long)tiles_x * tiles_y;
-    const long long local = (tiles - part + nparts - 1) / nparts;
+    const long long local = part_local_tiles(tiles, part, nparts);
     if (local <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((local + 3) / 4);
     hipLaunchKernelGGL(k_render_init, dim3(blocks), dim3(256), 0, st, rs, max_x, max_y, tiles_x, part, nparts, local);
@@ -1752,7 +1755,7 @@ hipError_t launch_trace(const DevScene& S, const DevTree& T, bool tree, const fl
 hipError_t launch_assemble(float* full, const float* parts, int max_x, int max_y, int nparts, hipStream_t st) {
     const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
     const long long tiles = (long long)tiles_x * tiles_y;
-    const long long per_part = (tiles + nparts - 1) / nparts * 64;
+    const long long per_part = part_local_tiles(tiles, 0, nparts) * 64;
     const unsigned blocks = (unsigned)((tiles + 3) / 4);
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, st, full, parts, max_x, max_y, tiles_x, nparts, per_part, tiles);
     return hipGetLastError();

@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
             const long long rank = blk * 64 + within % tiles_in_blk;
             const int l = (int)(within / tiles_in_blk);
             const long long local_tile = A.order ? (long long)A.order[rank] : rank;
-            const long long tile = A.part + local_tile * A.nparts;
+            const long long tile = part_tile(local_tile, A.part, A.nparts);
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
             const bool taken = use_long && A.long_flag[local_tile * 64 + l];      // long chains are handed out separately
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
         const long long pid = (long long)A.long_list[(unsigned int)(((unsigned long long)h * stride) % n_long)];
         const long long local_tile = pid >> 6;
         const int l = (int)(pid & 63);
-        const long long tile = A.part + local_tile * A.nparts;
+        const long long tile = part_tile(local_tile, A.part, A.nparts);
         const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
         i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
         idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_tile_cost_h(RenderArgs
     // a wave covers two tiles: 16 blocks x 2 samples each
     const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + lane / 32;
     const bool tile_ok = local_tile < A.n_local_tiles;
-    const long long tile = A.part + (tile_ok ? local_tile : 0) * A.nparts;
+    const long long tile = part_tile(tile_ok ? local_tile : 0, A.part, A.nparts);
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int sub = (lane % 32) / 2, smp = lane % 2;
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
@@ -947,7 +947,9 @@ __global__ __launch_bounds__(256) void k_assemble_h(uint16_t* full, const uint16
     const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
     const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
     if (i >= max_x || j >= max_y) return;
-    const long long src = (tile % nparts) * part_stride_px + (tile / nparts) * 64 + lane;
+    int owner; long long local_tile;
+    part_owner(tile, nparts, owner, local_tile);
+    const long long src = owner * part_stride_px + local_tile * 64 + lane;
     const long long dst = (long long)j * max_x + i;
     full[dst * 3 + 0] = parts[src * 3 + 0]; full[dst * 3 + 1] = parts[src * 3 + 1]; full[dst * 3 + 2] = parts[src * 3 + 2];
 }
@@ -1018,7 +1020,7 @@ hipError_t read_h16_stats(unsigned long long* out, int reset) {
 hipError_t launch_assemble_h(void* full, const void* parts, int max_x, int max_y, int nparts, hipStream_t st) {
     const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
     const long long tiles = (long long)tiles_x * tiles_y;
-    const long long per_part = (tiles + nparts - 1) / nparts * 64;
+    const long long per_part = part_local_tiles(tiles, 0, nparts) * 64;
     const unsigned blocks = (unsigned)((tiles + 3) / 4);
     hipLaunchKernelGGL(h16::k_assemble_h, dim3(blocks), dim3(256), 0, st, (uint16_t*)full, (const uint16_t*)parts, max_x, max_y, tiles_x, nparts, per_part, tiles);
     return hipGetLastError();

@@ -39,6 +39,7 @@ class Partition(C.Structure):
 
 
 WHOLE = Partition(0, 1)
+PART_RUN = 64          # rt_amd.h RT_PART_RUN: consecutive tiles per run of the tile split (tests restate the split with it)
 
 # every symbol include/rt_amd.h declares: (restype, argtypes)
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define RT_EINVAL (-1)
@@ -89,10 +89,16 @@ typedef struct rt_world rt_world;   /* device-resident scene: what d_list / d_wo
 typedef struct rt_octree rt_octree; /* Octree (acceleration_structure.h:57-62): host reference layout + device traversal copy */
 
 /* Which pixel tiles of the frame this call covers.  The frame is cut into 8x8-pixel tiles (the reference's
- * block shape, main.cu:351-352), numbered row-major from the bottom-left.  Tile t belongs to part (t % nparts).
+ * block shape, main.cu:351-352), numbered row-major from the bottom-left, and the tiles are dealt to the parts in runs of
+ * RT_PART_RUN consecutive tiles: tile t lies in run r = t / RT_PART_RUN, run r belongs to part (r % nparts) and is that part's
+ * (r / nparts)-th run.  (Runs rather than single tiles: the tiles a GPU renders side by side are neighbours in the image, as in
+ * the undivided frame — their rays meet the same spheres.  C5, the slowest of 8 parts on one MI355X: single tiles 106-110 ms,
+ * runs of 16: 104-110, of 64: 100-102, of 128: 101; whole frame / 8 = 83.)
  * nparts == 1: the whole frame, buffers in the reference's row-major layout (pixel_index = j*max_x + i).
- * nparts  > 1: buffers are tile-major and compact: element (local_tile*64 + ly*8 + lx), local_tile = t / nparts.
+ * nparts  > 1: buffers are tile-major and compact: element (local_tile*64 + ly*8 + lx),
+ *              local_tile = (r / nparts) * RT_PART_RUN + t % RT_PART_RUN.  Part 0 never has fewer tiles than another part.
  * rt_part_pixels() gives the element count of such a buffer. */
+#define RT_PART_RUN 64
 typedef struct rt_partition {
     int32_t part, nparts;
 } rt_partition;

@@ -14,12 +14,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
 
 
+PART_RUN = 64          # include/rt_amd.h RT_PART_RUN: tiles are dealt to the parts in runs of this many consecutive tiles
+
+
+def tile_owner(t, nparts):
+    """(part, local tile) of global tile t — the split rt_amd.h's rt_partition describes"""
+    run = t // PART_RUN
+    return run % nparts, (run // nparts) * PART_RUN + t % PART_RUN
+
+
 def part_pixels(nx, ny, part, nparts):
     """element count of the compact buffer of one part (what rt_part_pixels returns)"""
     if nparts == 1:
         return nx * ny
     tx, ty = (nx + 7) // 8, (ny + 7) // 8
-    return (tx * ty - part + nparts - 1) // nparts * 64
+    return sum(1 for t in range(tx * ty) if tile_owner(t, nparts)[0] == part) * 64
 
 
 def padded_part_pixels(nx, ny, nparts):
@@ -31,14 +40,15 @@ def local_pixel_ids(nx, ny, part, nparts, padded):
     """tile-major compact buffer of pixel_index values for one part (-1 = padding / outside the frame)"""
     tx, ty = (nx + 7) // 8, (ny + 7) // 8
     buf = np.full(padded, -1, np.int64)
-    lt = 0
-    for t in range(part, tx * ty, nparts):
+    for t in range(tx * ty):
+        owner, lt = tile_owner(t, nparts)
+        if owner != part:
+            continue
         x0, y0 = (t % tx) * 8, (t // tx) * 8
         for lane in range(64):
             i, j = x0 + (lane & 7), y0 + (lane >> 3)
             if i < nx and j < ny:
                 buf[lt * 64 + lane] = j * nx + i
-        lt += 1
     return buf
 
 
@@ -50,7 +60,8 @@ def assemble_numpy(parts, nx, ny, nparts, per):
         for lane in range(64):
             i, j = (t % tx) * 8 + (lane & 7), (t // tx) * 8 + (lane >> 3)
             if i < nx and j < ny:
-                full[j * nx + i] = parts[(t % nparts) * per + (t // nparts) * 64 + lane]
+                owner, lt = tile_owner(t, nparts)
+                full[j * nx + i] = parts[owner * per + lt * 64 + lane]
     return full
 
 
@@ -100,7 +111,8 @@ def test_two_rank_tile_split_gather_assemble(nx, ny):
 
 
 def test_partition_sizes_match_library(rt):
-    for nx, ny in ((1200, 800), (61, 35), (3840, 2160)):
+    assert rt.PART_RUN == PART_RUN
+    for nx, ny in ((1200, 800), (61, 35), (3840, 2160), (8, 8), (300, 9)):
         for nparts in (1, 2, 3, 4, 8):
             sizes = [rt.part_pixels(nx, ny, rt.Partition(p, nparts)) for p in range(nparts)]
             assert sizes == [part_pixels(nx, ny, p, nparts) for p in range(nparts)]

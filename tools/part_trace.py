@@ -1,0 +1,11 @@
+import os, sys
+sys.path.insert(0, "/root/repo/dd2360-raytracing_amd")
+import torch, rt_amd as rt
+nx, ny, n, spl, spp = 3840, 2160, 100000, 320, 256
+nparts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload()
+part = rt.Partition(0, nparts)
+st = rt.alloc_rand_state(nx, ny, part); fb = rt.alloc_fb(nx, ny, part)
+for rep in range(3):
+    rt.render_init(nx, ny, st, part); rt.render(fb, nx, ny, spp, W, st, O, part); torch.cuda.synchronize()
+print("kernel ms", W.render_times(), W.render_counters())

@@ -40,7 +40,7 @@ it = img[:, :, 0]
 print("per-pixel loop iterations: mean %.1f  p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f" % (it.mean(), *np.percentile(it, [50, 90, 99, 99.9]), it.max()))
 tend, tstart = img[:, :, 1].astype(np.float64), img[:, :, 2].astype(np.float64)
 t0_ = tstart.min()
-tend = ((tend - t0_) % 2**24) / 1e5; tstart = ((tstart - t0_) % 2**24) / 1e5          # ms since the first pixel started
+tend = ((tend - t0_) % 2**24) * 16 / 1e5; tstart = ((tstart - t0_) % 2**24) * 16 / 1e5          # ms since the first pixel started (the kernel stores 100 MHz ticks / 16)
 T = tend.max()
 print("pixel timing: frame ends at %.2f ms; pixels ending in the last 2 ms: %d, last 1 ms: %d" % (T, (tend > T - 2).sum(), (tend > T - 1).sum()))
 late = tend > T - 1.5
