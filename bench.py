@@ -7,7 +7,7 @@ inputs (scene, octree) already resident in HBM.
 N = 1   BASELINE config 3 (the config the metric is quoted on): 1200x800, 64 spp, NUM_SPHERES=10000, USE_OCTREE on,
         SPHERES_PER_LEAF=32, fp32.  --config c2|c4|c5 selects another BASELINE config for manual runs and profiles.
 N > 1   BASELINE config 5, STRONG scaling: the fixed 3840x2160 frame at 256 spp, NUM_SPHERES=100000, SPHERES_PER_LEAF=320 is
-        split over the N ranks (one process per GPU) by rt_multi_render of the C-ABI: 8x8 tiles dealt round-robin, each rank
+        split over the N ranks (one process per GPU) by rt_multi_render of the C-ABI: 8x8 tiles dealt round-robin in runs of 64, each rank
         renders its tiles into a compact buffer, ONE RCCL exchange (grouped ncclSend/ncclRecv over xGMI, issued by
         librt_amd.so on the render stream) brings the framebuffer to rank 0, which reassembles it — all inside the timed
         region.  torch.distributed (gloo, 127.0.0.1) only carries the RCCL id, the barriers and the max over ranks.
@@ -426,7 +426,7 @@ def main():
             workload += "; ARITHMETIC: FMA contraction allowed (RT_ARITH_CONTRACT) - a tolerance mode, NOT the pixel-identical parity mode"
         if world > 1:
             workload += ("; frame grown to %d x 960000 px" % world if weak else "; the fixed frame") + \
-                        ", 8x8 tiles round-robin over %d GPUs (rt_multi_render), one exchange to rank 0 over %s" % (world, transport)
+                        ", runs of 64 8x8 tiles round-robin over %d GPUs (rt_multi_render), one exchange to rank 0 over %s" % (world, transport)
         out = {
             "metric": "Msamples/s (W*H*spp/render_time) at %dx%d, %d spheres" % (nx, ny, cfg["spheres"]),
             "value": round(value, 3), "unit": "Msamples/s",

@@ -1,8 +1,8 @@
 // rt_multi.hip — one frame over the GPUs of a node: rt_multi_render (include/rt_amd.h).
 //
 // No reference counterpart (the reference is single-GPU); the launch surface it extends is main.cu:422-427.  One process per
-// GPU.  The frame's 8x8 tiles (the reference's block shape, main.cu:351-352) are dealt round-robin, tile t -> rank t % nranks,
-// so cheap sky tiles and expensive ground tiles mix on every GPU; pixels are independent (the per-pixel RNG is keyed by the
+// GPU.  The frame's 8x8 tiles (the reference's block shape, main.cu:351-352) are dealt round-robin in runs of RT_PART_RUN
+// consecutive tiles (rt_partition, rt_amd.h), so cheap sky tiles and expensive ground tiles mix on every GPU; pixels are independent (the per-pixel RNG is keyed by the
 // absolute pixel_index, main.cu:93), so every split gives the bits of the single-GPU frame.  Each rank renders its tiles
 // into a compact tile-major buffer (rt_partition) and ONE exchange brings the buffers to the root: with RCCL a single
 // ncclGroupStart / ncclRecv x (nranks-1) | ncclSend / ncclGroupEnd straight out of the render buffer and straight into the

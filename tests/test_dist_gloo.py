@@ -1,4 +1,4 @@
-"""N>1 path on CPU (not gpu): two gloo ranks split a frame by rt_multi_render's round-robin tile rule, gather the compact
+"""N>1 path on CPU (not gpu): two gloo ranks split a frame by rt_multi_render's tile rule (runs of tiles round-robin), gather the compact
 part buffers (equal padded sizes, one gather to rank 0 — the layout rt_multi_render's staging slots have) and rank 0 reassembles
 the frame.  The renderer is replaced by a pixel-id fill (the render itself needs a GPU: tests/test_gpu_multi.py runs the real
 rt_multi_render with 2 and 3 ranks); a numpy restatement of rt_assemble's index arithmetic (tests only) checks that every pixel
