@@ -91,7 +91,7 @@ def _worker(rank, world, port, nx, ny, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nx,ny", [(100, 52), (61, 35)])
+@pytest.mark.parametrize("nx,ny", [(100, 52), (61, 35), (640, 200)])      # 1.4 runs of tiles, less than one run (rank 1 owns nothing), 31 runs
 def test_two_rank_tile_split_gather_assemble(nx, ny):
     import torch.multiprocessing as mp
     s = socket.socket()

@@ -190,9 +190,10 @@ def test_render_init_states(rt, cuda):
 
 @pytest.mark.parametrize("nparts", [2, 3, 8])
 def test_partition_assemble_equals_whole(rt, cuda, nparts):
-    """tile partition (multi-GPU split) + rt_assemble reproduces the single-call frame bit for bit."""
+    """tile partition (multi-GPU split) + rt_assemble reproduces the single-call frame bit for bit.  700 x 330 = 3696 tiles = 57.75
+    runs of RT_PART_RUN tiles: several rounds of runs, an incomplete last round and a cut last run, ragged edge tiles."""
     torch = cuda
-    nx, ny, ns, n = 100, 52, 3, 500
+    nx, ny, ns, n = 700, 330, 3, 500
     W = rt.World(n, nx, ny)
     O = rt.Octree(W, 30)
     whole, _ = gpu_render(rt, torch, W, O, nx, ny, ns)
