@@ -186,7 +186,7 @@ struct WaveLds {
         unsigned short tp[64 * kPlaneStride];   // phase 1: per lane, the ray's parameter at every box plane of the tree
         struct {
             uint4 ray[128];              // phase 2: per owner (ox,oy,oz,dx) (dy,dz,a,-), every value in both halves of its dword
-            uint2 cq[kCand];             // candidates: (b | disc << 16 as binary16 bits, entry index + 1 << 6 | owner)
+            unsigned cq[kCand];          // candidates: entry index + 1 << 6 | owner
         } p2;
     } u;
     unsigned count, scount, pad_[2];
@@ -206,14 +206,45 @@ RT_DEV unsigned wave_excl_scan(unsigned v, unsigned& total) {   // exclusive pre
     return (unsigned)x - v;
 }
 
+struct PairRay { h2 ox, oy, oz, dx, dy, dz, a; };
+RT_DEV PairRay load_pair_ray(const WaveLds& L, int owner) {
+    const uint4 r0 = L.u.p2.ray[2 * owner], r1 = L.u.p2.ray[2 * owner + 1];
+    PairRay q;
+    q.ox = as_h2(r0.x); q.oy = as_h2(r0.y); q.oz = as_h2(r0.z); q.dx = as_h2(r0.w);
+    q.dy = as_h2(r1.x); q.dz = as_h2(r1.y); q.a = as_h2(r1.z);
+    return q;
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Two spheres against one ray: the discriminants of sphere.h:18-22 in packed binary16 (17 instructions); disc > 0 marks a candidate.
+// (A branch-free packed filter for spheres surely behind the origin — b > 0 and fl(b b) > fl(1.02 disc) — is exact but costs six
+// packed instructions per pair to drop a fifth of the candidates: measured in round 2, 75.8 against 76.6 ms, not kept.)
+RT_DEV void pair_math(const PairRay& q, const u32x4 p, h2& b, h2& disc) {
+    const h2 cx = as_h2(p.x), cy = as_h2(p.y), cz = as_h2(p.z), r2 = as_h2(p.w);
+    const h2 ocx = q.ox - cx, ocy = q.oy - cy, ocz = q.oz - cz;
+    b = (ocx * q.dx + ocy * q.dy) + ocz * q.dz;
+    const h2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
+    const h2 bb = b * b;
+    disc = bb - q.a * cc;
+}
+
 // One queued candidate: the offer of sphere::hit (sphere.h:24-43) for a positive discriminant, merged into its owner's key.
-RT_DEV void candidate_eval(WaveLds& L, const uint2 e) {
+// (A record of the queue is the candidate's entry and its owner; b and the discriminant are computed again here, from the pair and the
+// owner's ray — the same packed operations on the same operands, so the same bits — at 64 candidates per pass of the wave: cheaper
+// than picking the two words out of a lane's four pairs when the record is written, ~20 instructions of a 32-instruction turn.)
+RT_DEV void candidate_eval(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, const uint32_t rec) {
     H16_CNT(5, 1);
-    const int owner = (int)(e.y & 63u);
-    const uint32_t idx1 = e.y >> 6;
+    const int owner = (int)(rec & 63u);
+    const uint32_t idx1 = rec >> 6;
+    const uint32_t e0 = idx1 - 1u;                             // entry: pair e0 / 2, half e0 & 1
+    const u32x4 pr = __builtin_amdgcn_raw_buffer_load_b128(ent, (int)((e0 >> 1) * 16u), 0, 0);
+    const PairRay q = load_pair_ray(L, owner);
+    h2 pb, pd;
+    pair_math(q, pr, pb, pd);
+    const uint32_t sh = (e0 & 1u) * 16u;
     R hb, hd, ha, hbest;
-    hb.bits = (uint16_t)e.x; hd.bits = (uint16_t)(e.x >> 16);
-    ha.bits = (uint16_t)L.u.p2.ray[2 * owner + 1].z;
+    hb.bits = (uint16_t)(h2_bits(pb) >> sh); hd.bits = (uint16_t)(h2_bits(pd) >> sh);
+    ha.bits = (uint16_t)h2_bits(q.a);
     hbest.bits = (uint16_t)(((const unsigned*)&L.key[owner])[1]);
     const float b_f = fl(hb), d_f = fl(hd), A = fl(ha), best_f = fl(hbest);
     if (!(d_f > 0.0f)) return;                                // sphere.h:23 (the packed positive test of push_pass lets a -0 through)
@@ -237,12 +268,12 @@ RT_DEV void candidate_eval(WaveLds& L, const uint2 e) {
 }
 
 // all queued candidates, 64 at a time
-RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
+RT_DEV void drain_candidates(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int lane, unsigned& qn) {
     wave_sync();
     const unsigned cnt = min(qn, (unsigned)kCand);
     for (unsigned base = 0; base < cnt; base += 64u) {
         const unsigned i = base + (unsigned)lane;
-        if (i < cnt) candidate_eval(L, L.u.p2.cq[i]);
+        if (i < cnt) candidate_eval(L, ent, L.u.p2.cq[i]);
     }
     qn = 0u;
     wave_sync();
@@ -254,63 +285,45 @@ RT_DEV void drain_candidates(WaveLds& L, int lane, unsigned& qn) {
 // (Before: one ballot + mbcnt block per sphere slot, eight per pass, ~10 vector and ~11 scalar instructions each, and the candidate
 // evaluation inlined in each of them for a full queue.)
 // (the pairs' b and discriminant words come by value — arrays indexed by a lane's own bit position would live in scratch memory)
-template <int NP, int STRIDE>
-RT_DEV void push_pass(WaveLds& L, int lane, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
-                      unsigned pair0, int owner, unsigned& qn) {
+// bit k (x halves) / 16 + k (y halves) for every positive discriminant among the NP pairs of a pass that lie inside the lane's range
+// (the first `nb` of them: a pass may read past its segment, and what it computes there is masked here, once, not per pair)
+template <int NP>
+RT_DEV uint32_t pass_mask(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, unsigned nb) {
     static_assert(NP >= 1 && NP <= 4, "positions 0-3 (x halves) and 16-19 (y halves) of the mask");
     const uint32_t dd[4] = {d0, d1, d2, d3};
     uint32_t acc = 0u;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const uint32_t pos = h2_bits(__builtin_elementwise_max(as_h2(dd[k]), as_h2(0u)));      // v_pk_max_f16: 0 for a negative or NaN half
-        uint32_t one;                                                                          // 1 in every half that is not 0
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(pos), "v"(0x00010001u));               // (written out: the optimiser turns the C form back into compares)
+        uint32_t pos, one;
+        // v_pk_max_f16 with 0: 0 for a negative half and for a NaN one (maxNum: a discriminant is the result of an addition, a quiet NaN
+        // if any); written out — the C form gets a canonicalising v_pk_max_f16 x, x in front for signalling NaNs that cannot occur here,
+        // and the optimiser turns the min_u16 (1 in every half that is not 0) back into compares
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(pos) : "v"(dd[k]));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(pos), "v"(0x00010001u));
         acc |= one << k;
     }
+    return acc & (((1u << nb) - 1u) * 0x00010001u);
+}
+
+template <int STRIDE>
+RT_DEV void push_pass(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int lane, uint32_t acc, unsigned pair0, int owner, unsigned& qn) {
     // one record per lane and turn, the lanes that still hold a positive taking consecutive slots (ballot + mbcnt): two turns a
     // pass on average; a turn that does not fit the queue drains it first — no candidate is evaluated in place
     while (true) {
         const unsigned long long m = __ballot(acc != 0u);
         if (m == 0ull) break;
         const unsigned n = (unsigned)__popcll(m);
-        if (qn + n > (unsigned)kCand) drain_candidates(L, lane, qn);
+        if (qn + n > (unsigned)kCand) drain_candidates(L, ent, lane, qn);
         if (acc != 0u) {
             const int p = __builtin_ctz(acc);
             acc &= acc - 1u;
             const int pr = p & 3, hi = p >> 4;                // pair of the pass, half of the pair
-            // pair pr of the pass by two levels of selects (v_cndmask), not a chain of branches
-            const bool p1 = (pr & 1) != 0, p2 = (pr & 2) != 0;
-            const uint32_t b01 = p1 ? b1 : b0, b23 = p1 ? b3 : b2, d01 = p1 ? d1 : d0, d23 = p1 ? d3 : d2;
-            const uint32_t bw = p2 ? b23 : b01, dw = p2 ? d23 : d01;
-            const uint32_t rec = hi ? ((bw >> 16) | (dw & 0xffff0000u)) : ((bw & 0xffffu) | (dw << 16));
             const uint32_t idx1 = (pair0 + (unsigned)(pr * STRIDE)) * 2u + 1u + (unsigned)hi;       // (this lane's pairs of the pass are STRIDE apart)
             const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            L.u.p2.cq[slot] = make_uint2(rec, (idx1 << 6) | (uint32_t)owner);
+            L.u.p2.cq[slot] = (idx1 << 6) | (uint32_t)owner;
         }
         qn += n;
     }
-}
-
-struct PairRay { h2 ox, oy, oz, dx, dy, dz, a; };
-RT_DEV PairRay load_pair_ray(const WaveLds& L, int owner) {
-    const uint4 r0 = L.u.p2.ray[2 * owner], r1 = L.u.p2.ray[2 * owner + 1];
-    PairRay q;
-    q.ox = as_h2(r0.x); q.oy = as_h2(r0.y); q.oz = as_h2(r0.z); q.dx = as_h2(r0.w);
-    q.dy = as_h2(r1.x); q.dz = as_h2(r1.y); q.a = as_h2(r1.z);
-    return q;
-}
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Two spheres against one ray: the discriminants of sphere.h:18-22 in packed binary16 (17 instructions); disc > 0 marks a candidate.
-// (A branch-free packed filter for spheres surely behind the origin — b > 0 and fl(b b) > fl(1.02 disc) — is exact but costs six
-// packed instructions per pair to drop a fifth of the candidates: measured in round 2, 75.8 against 76.6 ms, not kept.)
-RT_DEV void pair_math(const PairRay& q, const u32x4 p, h2& b, h2& disc) {
-    const h2 cx = as_h2(p.x), cy = as_h2(p.y), cz = as_h2(p.z), r2 = as_h2(p.w);
-    const h2 ocx = q.ox - cx, ocy = q.oy - cy, ocz = q.oz - cz;
-    b = (ocx * q.dx + ocy * q.dy) + ocz * q.dz;
-    const h2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
-    const h2 bb = b * b;
-    disc = bb - q.a * cc;
 }
 
 // intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
@@ -573,18 +586,12 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
 #pragma unroll
                 for (int k = 0; k < kPP; ++k) e[k] = __builtin_amdgcn_raw_buffer_load_b128(ent, voff, 16 * k, 0);
                 h2 b[kPP], d[kPP];
-                h2 vm = as_h2(0u);
 #pragma unroll
-                for (int k = 0; k < kPP; ++k) {
-                    pair_math(q, e[k], b[k], d[k]);
-                    if ((unsigned)k >= nb) d[k] = as_h2(0u);
-                    vm = __builtin_elementwise_max(vm, d[k]);          // (maxNum: a NaN discriminant loses)
-                }
-                if (__ballot(h2_bits(vm) != 0u) != 0ull)
-                    push_pass<kPP, 1>(L, lane, h2_bits(b[0]), h2_bits(b[kPP > 1 ? 1 : 0]), h2_bits(b[kPP > 2 ? 2 : 0]), h2_bits(b[kPP > 3 ? 3 : 0]),
-                                      h2_bits(d[0]), h2_bits(d[kPP > 1 ? 1 : 0]), h2_bits(d[kPP > 2 ? 2 : 0]), h2_bits(d[kPP > 3 ? 3 : 0]), i0, owner, qn);
+                for (int k = 0; k < kPP; ++k) pair_math(q, e[k], b[k], d[k]);
+                const uint32_t acc = pass_mask<kPP>(h2_bits(d[0]), h2_bits(d[kPP > 1 ? 1 : 0]), h2_bits(d[kPP > 2 ? 2 : 0]), h2_bits(d[kPP > 3 ? 3 : 0]), nb);
+                if (__ballot(acc != 0u) != 0ull) push_pass<1>(L, ent, lane, acc, i0, owner, qn);
                 cur += nb;
-                if (qn >= 64u) drain_candidates(L, lane, qn);
+                if (qn >= 64u) drain_candidates(L, ent, lane, qn);
             }
         }
         // ---- phase 2b: the small segments, one per lane (their pairs one after the other: mostly one)
@@ -600,12 +607,12 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(ent, (int)(ix * 16u), 0, 0);
                 h2 b, d;
                 pair_math(q, e, b, d);
-                if (!act) d = as_h2(0u);
-                if (__ballot(h2_bits(__builtin_elementwise_max(as_h2(0u), d)) != 0u) != 0ull) push_pass<1, 1>(L, lane, h2_bits(b), 0u, 0u, 0u, h2_bits(d), 0u, 0u, 0u, ix, owner, qn);
-                if (qn >= 64u) drain_candidates(L, lane, qn);
+                const uint32_t acc = pass_mask<1>(h2_bits(d), 0u, 0u, 0u, act ? 1u : 0u);
+                if (__ballot(acc != 0u) != 0ull) push_pass<1>(L, ent, lane, acc, ix, owner, qn);
+                if (qn >= 64u) drain_candidates(L, ent, lane, qn);
             }
         }
-        drain_candidates(L, lane, qn);
+        drain_candidates(L, ent, lane, qn);
         H16_ADD(2, tph);                                             // tests
         // ---- phase 3
         const unsigned long long k = L.key[lane];
