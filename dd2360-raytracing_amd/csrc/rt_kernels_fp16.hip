@@ -288,9 +288,8 @@ RT_DEV void drain_candidates(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int l
 // bit k (x halves) / 16 + k (y halves) for every positive discriminant among the NP pairs of a pass that lie inside the lane's range
 // (the first `nb` of them: a pass may read past its segment, and what it computes there is masked here, once, not per pair)
 template <int NP>
-RT_DEV uint32_t pass_mask(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, unsigned nb) {
-    static_assert(NP >= 1 && NP <= 4, "positions 0-3 (x halves) and 16-19 (y halves) of the mask");
-    const uint32_t dd[4] = {d0, d1, d2, d3};
+RT_DEV uint32_t pass_mask(const h2 (&d)[NP], unsigned nb) {
+    static_assert(NP >= 1 && NP <= 16, "positions 0-15 (x halves) and 16-31 (y halves) of the mask");
     uint32_t acc = 0u;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -298,7 +297,7 @@ RT_DEV uint32_t pass_mask(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, un
         // v_pk_max_f16 with 0: 0 for a negative half and for a NaN one (maxNum: a discriminant is the result of an addition, a quiet NaN
         // if any); written out — the C form gets a canonicalising v_pk_max_f16 x, x in front for signalling NaNs that cannot occur here,
         // and the optimiser turns the min_u16 (1 in every half that is not 0) back into compares
-        asm("v_pk_max_f16 %0, %1, 0" : "=v"(pos) : "v"(dd[k]));
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(pos) : "v"(h2_bits(d[k])));
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(pos), "v"(0x00010001u));
         acc |= one << k;
     }
@@ -317,7 +316,7 @@ RT_DEV void push_pass(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int lane, ui
         if (acc != 0u) {
             const int p = __builtin_ctz(acc);
             acc &= acc - 1u;
-            const int pr = p & 3, hi = p >> 4;                // pair of the pass, half of the pair
+            const int pr = p & 15, hi = p >> 4;               // pair of the pass, half of the pair
             const uint32_t idx1 = (pair0 + (unsigned)(pr * STRIDE)) * 2u + 1u + (unsigned)hi;       // (this lane's pairs of the pass are STRIDE apart)
             const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             L.u.p2.cq[slot] = (idx1 << 6) | (uint32_t)owner;
@@ -588,7 +587,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 h2 b[kPP], d[kPP];
 #pragma unroll
                 for (int k = 0; k < kPP; ++k) pair_math(q, e[k], b[k], d[k]);
-                const uint32_t acc = pass_mask<kPP>(h2_bits(d[0]), h2_bits(d[kPP > 1 ? 1 : 0]), h2_bits(d[kPP > 2 ? 2 : 0]), h2_bits(d[kPP > 3 ? 3 : 0]), nb);
+                const uint32_t acc = pass_mask<kPP>(d, nb);
                 if (__ballot(acc != 0u) != 0ull) push_pass<1>(L, ent, lane, acc, i0, owner, qn);
                 cur += nb;
                 if (qn >= 64u) drain_candidates(L, ent, lane, qn);
@@ -605,9 +604,9 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 const bool act = k < cnt;
                 const unsigned ix = act ? first + k : 0u;
                 const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(ent, (int)(ix * 16u), 0, 0);
-                h2 b, d;
-                pair_math(q, e, b, d);
-                const uint32_t acc = pass_mask<1>(h2_bits(d), 0u, 0u, 0u, act ? 1u : 0u);
+                h2 b, d[1];
+                pair_math(q, e, b, d[0]);
+                const uint32_t acc = pass_mask<1>(d, act ? 1u : 0u);
                 if (__ballot(acc != 0u) != 0ull) push_pass<1>(L, ent, lane, acc, ix, owner, qn);
                 if (qn >= 64u) drain_candidates(L, ent, lane, qn);
             }
