@@ -168,11 +168,14 @@ __device__ unsigned long long g_h16_cyc[8];
 #define H16_ADD(k, t0) do { const unsigned long long now_ = H16_TICK(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_h16_cyc[k], now_ - (t0)); (t0) = now_; } while (0)
 #ifdef RT_H16_COUNTS           // (per-lane atomics: distort every timing of the same run)
 #define H16_CNT(k, v) atomicAdd(&g_h16_cyc[k], (unsigned long long)(v))
+#define H16_FIRST_ACTIVE() ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true)))
 #else
 #define H16_CNT(k, v) ((void)0)
+#define H16_FIRST_ACTIVE() false
 #endif
 #else
 #define H16_CNT(k, v) ((void)0)
+#define H16_FIRST_ACTIVE() false
 #define H16_TICK() 0ull
 #define H16_ADD(k, t0) ((void)0)
 #endif
@@ -482,6 +485,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             bool room = pool_leaves();                                  // (left over from the previous round)
             while (room && lvl >= 0) {                                  // lvl 0: inside the root, 1: inside the level-1 node wn1
                 const unsigned m = lvl == 0 ? wm0 : wm1;
+                H16_CNT(4, 1); if (H16_FIRST_ACTIVE()) H16_CNT(7, 1);       // (counts build: lane trips / wave trips of this loop)
                 if (m == 0u) { --lvl; continue; }
                 const int c = __builtin_ctz(m);
                 const int child = (int)s_child16[(lvl == 0 ? 0 : wn1) * 8 + c];
