@@ -328,6 +328,25 @@ RT_DEV void push_pass(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int lane, ui
     }
 }
 
+// float division by a divisor that serves several quotients.  The compiler's IEEE division is v_div_scale_f32 x 2, v_rcp_f32, two
+// multiply-adds refining the reciprocal, five forming the quotient, v_div_fmas_f32, v_div_fixup_f32; for operands that came from
+// binary16 (magnitudes in [2^-24, 65504], or 0 / inf / NaN) the scale factors are always 1, so the scaling drops out and the refined
+// reciprocal can be shared: the same multiply-adds on the same values.  tools/micro/div_shared.hip compares the two forms for all
+// 2^32 pairs of binary16 operands on the GPU: no quotient differs, in float or rounded to binary16.
+struct DivBy { float d, r; };
+RT_DEV DivBy div_prepare(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return {d, __builtin_fmaf(e, r0, r0)};
+}
+RT_DEV float div_by(float n, const DivBy& D) {
+    float q = n * D.r;
+    float rem = __builtin_fmaf(-D.d, q, n);
+    q = __builtin_fmaf(rem, D.r, q);
+    rem = __builtin_fmaf(-D.d, q, n);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(rem, D.r, q), D.d, n);
+}
+
 // intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
 RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
     auto T = [&](int q) { R h; h.bits = tp[(w >> (5 * q)) & 31u]; return fl(h); };
@@ -434,8 +453,8 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     const bool regular = regular_planes(T);
     // the walk of a regular tree (below): which level the lane is expanding (-1: done, -2: not started), the level-1 and level-2
     // nodes it is inside, and per level the children that passed and are still to be visited
-    int lvl = live ? -2 : -1, wn1 = 0, wn2 = 0;
-    unsigned wm0 = 0u, wm1 = 0u, wm2 = 0u;
+    // (between the walks of two rounds the six values live packed in two registers: the test loop needs every register it can get)
+    uint32_t ws_m = (live ? 0u : 1u) << 24, ws_n = 0u;          // wm0 | wm1 << 8 | wm2 << 16 | (lvl + 2) << 24;  wn1 | wn2 << 16
     const unsigned short* s_child16 = (const unsigned short*)(s_nodes + n_nodes);
     unsigned short* tp = L.u.tp + lane * kPlaneStride;
     while (true) {
@@ -444,15 +463,22 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         if (np0 > 0) {
             // the ray's parameter at every box plane: the quotients intersect_ray_aabb forms, one division per plane
             const float* __restrict__ pl = T.h16_planes;
-            for (int k = 0; k < np0; ++k) tp[k] = ((rf(pl[k]) - r.o.x) / r.d.x).bits;
-            for (int k = 0; k < np1; ++k) tp[np0 + k] = ((rf(pl[np0 + k]) - r.o.y) / r.d.y).bits;
-            for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = ((rf(pl[np0 + np1 + k]) - r.o.z) / r.d.z).bits;
+            // (nine quotients per divisor: div_by — the compiler's IEEE division without its scaling steps and with the refined
+            // reciprocal shared; bit-identical for every pair of binary16 operands, tools/micro/div_shared.hip)
+            { const DivBy D = div_prepare(fl(r.d.x));
+_Pragma("unroll 1") for (int k = 0; k < np0; ++k) tp[k] = rf(div_by(fl(rf(pl[k]) - r.o.x), D)).bits; }
+            { const DivBy D = div_prepare(fl(r.d.y));
+_Pragma("unroll 1") for (int k = 0; k < np1; ++k) tp[np0 + k] = rf(div_by(fl(rf(pl[np0 + k]) - r.o.y), D)).bits; }
+            { const DivBy D = div_prepare(fl(r.d.z));
+_Pragma("unroll 1") for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = rf(div_by(fl(rf(pl[np0 + np1 + k]) - r.o.z), D)).bits; }
         }
         wave_sync();
         // ---- phase 1: walk; every visited non-empty level-3 node becomes a segment of one of the pools (or stalls the lane when that
         //      pool is full).  traverseTree (acceleration_structure.h:276-304) visits a node's non-zero children in index order,
         //      each after its own slab test; which nodes are visited does not depend on the order, and neither does the result (above).
         if (regular) {
+            int lvl = (int)(ws_m >> 24) - 2, wn1 = (int)(ws_n & 0xffffu), wn2 = (int)(ws_n >> 16);
+            unsigned wm0 = ws_m & 255u, wm1 = (ws_m >> 8) & 255u, wm2 = (ws_m >> 16) & 255u;
             // A step of the lane is either the expansion of an inner node — its eight children's slab tests at once — or the visit
             // of a level-3 child that passed: ~11 steps a ray instead of one dependent LDS chain per tested node (27 a ray).
             if (lvl == -2) {
@@ -496,6 +522,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                 else { wn2 = child; wm2 = cm; room = pool_leaves(); }
             }
             if (lvl < 0 && wm2 == 0u) node = n_nodes;
+            ws_m = wm0 | (wm1 << 8) | (wm2 << 16) | ((uint32_t)(lvl + 2) << 24); ws_n = (uint32_t)wn1 | ((uint32_t)wn2 << 16);
         } else
         while (node < n_nodes) {
             bool pass; int skip; uint32_t first; unsigned cnt;
