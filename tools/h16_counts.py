@@ -1,5 +1,6 @@
+"""Candidate and walk-loop counts of a C4 frame (counts build: tools/mkvariant.sh h16counts -DRT_H16_STATS -DRT_H16_COUNTS, loaded through RT_AMD_LIB)."""
 import ctypes as C, os, sys
-sys.path.insert(0, "/root/repo/dd2360-raytracing_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dd2360-raytracing_amd"))
 import torch, rt_amd as rt
 nx, ny, ns, n, spl = 1200, 800, 16, 10000, 32
 W = rt.World(n, nx, ny, precision=rt.FP16); O = rt.Octree(W, spl)

@@ -1,5 +1,6 @@
+"""Three renders of part 0 of N of the C5 frame (for rocprofv3: tools/part_kernels.sh, tools/pmc_part.sh).  usage: part_trace.py [nparts]"""
 import os, sys
-sys.path.insert(0, "/root/repo/dd2360-raytracing_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dd2360-raytracing_amd"))
 import torch, rt_amd as rt
 nx, ny, n, spl, spp = 3840, 2160, 100000, 320, 256
 nparts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
