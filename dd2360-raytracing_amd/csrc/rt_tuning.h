@@ -91,7 +91,7 @@
 
 // ---- USE_FP16 (rt_kernels_fp16.hip) -----------------------------------------------------------------------------
 #ifndef RT_H16_MINWAVES
-#define RT_H16_MINWAVES 4       // waves per SIMD k_render_h is compiled for (5, 6 with spills: no change)
+#define RT_H16_MINWAVES 4       // waves per SIMD k_render_h is compiled for (5, 6 with spills: no change; 3: 40.6 ms against 37.1, 40.1 with 12 pairs per pass)
 #endif
 #ifndef RT_H16_BIG
 #define RT_H16_BIG 128          // big segments (bucket ranges of >= 8 pairs) a wave pools per round (a multiple of 64, at most 128)
