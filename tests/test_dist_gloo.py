@@ -91,8 +91,10 @@ def _worker(rank, world, port, nx, ny, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nx,ny", [(100, 52), (61, 35), (640, 200)])      # 1.4 runs of tiles, less than one run (rank 1 owns nothing), 31 runs
-def test_two_rank_tile_split_gather_assemble(nx, ny):
+# two ranks: 1.4 runs of tiles, less than one run (rank 1 owns nothing), 31 runs; eight ranks (the north star's node): 31 runs = three
+# full rounds and an incomplete one, parts of different sizes
+@pytest.mark.parametrize("world,nx,ny", [(2, 100, 52), (2, 61, 35), (2, 640, 200), (8, 640, 200)])
+def test_tile_split_gather_assemble_over_gloo(world, nx, ny):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -100,14 +102,14 @@ def test_two_rank_tile_split_gather_assemble(nx, ny):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, nx, ny, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def test_partition_sizes_match_library(rt):
