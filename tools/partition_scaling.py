@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
 import torch
 import rt_amd as rt
-nx, ny, n, spl = 3840, 2160, 100000, 320
+nx, ny, n, spl = int(os.environ.get('RT_NX', 3840)), 2160, 100000, 320      # RT_NX: another frame width (how the runs of a part stack from row to row depends on it)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 W = rt.World(n, nx, ny).upload(); O = rt.Octree(W, spl).upload()
 base = None
