@@ -141,11 +141,11 @@ RT_DEV void closest_list(const DevScene& S, const Ray& r, R a, R& closest, int& 
 // (closest_so_far << 32 | 0) — what the ray holds already (the ground sphere, earlier rounds) wins ties like in the scan.
 // Tests run two spheres at a time in packed binary16 (v_pk_add_f16 / v_pk_mul_f16: one rounding per operation, the same bits
 // as the float-and-round form of rt_real.h).  A positive discriminant is rare (3 % of the tests) and expensive (correctly
-// rounded sqrt, two IEEE divisions), so the test loop never evaluates it in place — 8 sub-slots per pass, each with one or two
-// of the 64 lanes interested, cost 4x the packed arithmetic: a branch-free packed filter first drops spheres surely behind the
-// origin (below), what is left goes into a queue of the wave (LDS), and whenever 64 candidates have gathered all 64 lanes
-// take one each: a cheap float filter against the owner's best so far, then the reference's roots, then an LDS atomic min on
-// the owner's key.
+// rounded sqrt, two IEEE divisions), so the test loop never evaluates it in place — 16 sub-slots per pass, each with one or two
+// of the 64 lanes interested, would cost several times the packed arithmetic: a packed test marks the positive halves of a pass
+// (pass_mask), their entries go into a queue of the wave (LDS: push_pass), and whenever 64 candidates have gathered all 64 lanes
+// take one each (candidate_eval): b and the discriminant again from the pair, a cheap float filter against the owner's best so far,
+// then the reference's roots, then an LDS atomic min on the owner's key.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 RT_DEV h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
 RT_DEV uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -156,7 +156,7 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // pairs, 56 upper cells holding one large sphere each): BIG segments are concatenated and dealt out in equal spans, kPP pairs per
 // lane and pass; SMALL ones (fewer than kSmallPairs pairs) would break every span they fall into — a pass cannot cross a segment
 // boundary — so they go to a pool of their own and are tested one segment per lane.  (One pool for both: 1 pair per pass was the
-// fastest setting, 80.0 ms against 96.6 with 4, because most segments were tiny; split: 4 pairs per pass on the big ones.)
+// fastest setting, 80.0 ms against 96.6 with 4, because most segments were tiny; split: kPP (eight) pairs per pass on the big ones.)
 constexpr int kBig = RT_H16_BIG;                              // big segments per wave and round (a multiple of 64)
 constexpr int kSmall = RT_H16_SMALL;                          // small segments per wave and round
 constexpr unsigned kSmallPairs = 8u;                          // a node with fewer pairs is a small segment (its count must fit 3 bits)
@@ -234,7 +234,7 @@ RT_DEV void pair_math(const PairRay& q, const u32x4 p, h2& b, h2& disc) {
 // One queued candidate: the offer of sphere::hit (sphere.h:24-43) for a positive discriminant, merged into its owner's key.
 // (A record of the queue is the candidate's entry and its owner; b and the discriminant are computed again here, from the pair and the
 // owner's ray — the same packed operations on the same operands, so the same bits — at 64 candidates per pass of the wave: cheaper
-// than picking the two words out of a lane's four pairs when the record is written, ~20 instructions of a 32-instruction turn.)
+// than picking the two words out of a lane's pairs when the record is written: ~20 instructions of a 32-instruction turn then.)
 RT_DEV void candidate_eval(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, const uint32_t rec) {
     H16_CNT(5, 1);
     const int owner = (int)(rec & 63u);
@@ -250,7 +250,7 @@ RT_DEV void candidate_eval(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, const u
     ha.bits = (uint16_t)h2_bits(q.a);
     hbest.bits = (uint16_t)(((const unsigned*)&L.key[owner])[1]);
     const float b_f = fl(hb), d_f = fl(hd), A = fl(ha), best_f = fl(hbest);
-    if (!(d_f > 0.0f)) return;                                // sphere.h:23 (the packed positive test of push_pass lets a -0 through)
+    if (!(d_f > 0.0f)) return;                                // sphere.h:23 (the packed positive test of pass_mask lets a -0 through)
     const float nb = -b_f;
     // cheap filter, margin >= 2x its own error (half an ulp of binary16 on sqrt: 4.9e-4 s; float roundings ~1e-7)
     const float ra = __builtin_amdgcn_rcpf(A);
@@ -285,9 +285,9 @@ RT_DEV void drain_candidates(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int l
 // The positive discriminants of one pass — NP pairs per lane, i.e. up to 2 NP spheres — go into the wave's candidate queue.  One
 // place for all of them: a packed test marks the positive halves (max(disc, 0) is 0 for a negative or NaN discriminant; min_u16 with
 // 1 turns every other half into a 1), then every lane writes its own records, lowest sphere first.
-// (Before: one ballot + mbcnt block per sphere slot, eight per pass, ~10 vector and ~11 scalar instructions each, and the candidate
-// evaluation inlined in each of them for a full queue.)
-// (the pairs' b and discriminant words come by value — arrays indexed by a lane's own bit position would live in scratch memory)
+// (Round 2: one ballot + mbcnt block per sphere slot, eight per pass, ~10 vector and ~11 scalar instructions each, and the candidate
+// evaluation inlined in each of them for a full queue.  Until the end of round 3 a record also carried the pair's b and
+// discriminant words, picked out of the lane's pairs by a chain of selects: see candidate_eval.)
 // bit k (x halves) / 16 + k (y halves) for every positive discriminant among the NP pairs of a pass that lie inside the lane's range
 // (the first `nb` of them: a pass may read past its segment, and what it computes there is masked here, once, not per pair)
 template <int NP>
