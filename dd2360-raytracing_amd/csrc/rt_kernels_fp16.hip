@@ -349,16 +349,17 @@ RT_DEV float div_by(float n, const DivBy& D) {
 
 // intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
 RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
-    auto T = [&](int q) { R h; h.bits = tp[(w >> (5 * q)) & 31u]; return fl(h); };
-    float tmin = T(0), tmax = T(1);
-    if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
-    float tymin = T(2), tymax = T(3);
-    if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
+    typedef _Float16 H;                                          // (compared as binary16: see expand_node)
+    auto T = [&](int q) { return __builtin_bit_cast(H, tp[(w >> (5 * q)) & 31u]); };
+    H tmin = T(0), tmax = T(1);
+    if (tmin > tmax) { const H t = tmin; tmin = tmax; tmax = t; }
+    H tymin = T(2), tymax = T(3);
+    if (tymin > tymax) { const H t = tymin; tymin = tymax; tymax = t; }
     if ((tmin > tymax) || (tymin > tmax)) return false;
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
-    float tzmin = T(4), tzmax = T(5);
-    if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
+    H tzmin = T(4), tzmax = T(5);
+    if (tzmin > tzmax) { const H t = tzmin; tzmin = tzmax; tzmax = t; }
     if ((tmin > tzmax) || (tzmin > tmax)) return false;
     return true;
 }
@@ -410,19 +411,22 @@ RT_DEV WaveLds* stage_tree(const DevTree& T, float4* s_nodes) {
 // ray_box_tab computes of its six parameters — the same comparisons in the same order, shared where children share a half.
 // Returns the children that pass, bit 4 (x high) + 2 (y high) + (z high) — acceleration_structure.h:149-165.
 RT_DEV unsigned expand_node(const unsigned short* tp, uint32_t w) {
-    auto T = [&](uint32_t i) { R h; h.bits = tp[i]; return fl(h); };
+    // (the parameters are compared as the binary16 values they are: the conversion to float is exact and order-preserving, NaNs included,
+    // so v_cmp_*_f16 on the stored bits decides what the reference's float comparisons decide — nine conversions less per expansion)
+    typedef _Float16 H;
+    auto T = [&](uint32_t i) { return __builtin_bit_cast(H, tp[i]); };
     const uint32_t i0 = w & 31u, i1 = (w >> 5) & 31u, j0 = (w >> 10) & 31u, j1 = (w >> 15) & 31u, k0 = (w >> 20) & 31u, k1 = (w >> 25) & 31u;
-    const float tx0 = T(i0), txm = T((i0 + i1) >> 1), tx1 = T(i1), ty0 = T(j0), tym = T((j0 + j1) >> 1), ty1 = T(j1), tz0 = T(k0), tzm = T((k0 + k1) >> 1), tz1 = T(k1);
-    float lo[3][2], hi[3][2];                                    // [axis][half]: the slab interval after the reference's swap
-    auto slab = [&](int ax, int h, float a, float b) { if (a > b) { const float t = a; a = b; b = t; } lo[ax][h] = a; hi[ax][h] = b; };
+    const H tx0 = T(i0), txm = T((i0 + i1) >> 1), tx1 = T(i1), ty0 = T(j0), tym = T((j0 + j1) >> 1), ty1 = T(j1), tz0 = T(k0), tzm = T((k0 + k1) >> 1), tz1 = T(k1);
+    H lo[3][2], hi[3][2];                                        // [axis][half]: the slab interval after the reference's swap
+    auto slab = [&](int ax, int h, H a, H b) { if (a > b) { const H t = a; a = b; b = t; } lo[ax][h] = a; hi[ax][h] = b; };
     slab(0, 0, tx0, txm); slab(0, 1, txm, tx1); slab(1, 0, ty0, tym); slab(1, 1, tym, ty1); slab(2, 0, tz0, tzm); slab(2, 1, tzm, tz1);
     unsigned mask = 0u;
 #pragma unroll
     for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
         for (int yh = 0; yh < 2; ++yh) {
-            float tmin = lo[0][xh], tmax = hi[0][xh];
-            const float tymin = lo[1][yh], tymax = hi[1][yh];
+            H tmin = lo[0][xh], tmax = hi[0][xh];
+            const H tymin = lo[1][yh], tymax = hi[1][yh];
             const bool xy = !((tmin > tymax) || (tymin > tmax));
             if (tymin > tmin) tmin = tymin;
             if (tymax < tmax) tmax = tymax;
