@@ -368,6 +368,7 @@ RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {
 // skip link, first pair, pairs, the six plane indices — and they are staged as ONE 16-byte record per node (one ds_read_b128 a
 // visit instead of three, 2.5 KB instead of 7.5 KB at C4); a tree without the table keeps the full 48-byte nodes (boxes for ray_box).
 // Returns the calling wave's pool, which follows the nodes.
+constexpr int kPlaneLds4 = 8;                                 // float4 slots for the tree's planes in LDS (at most 30 planes: kPlaneStride)
 RT_DEV bool regular_planes(const DevTree& T) { return T.h16_np[0] == 9 && T.h16_np[1] == 9 && T.h16_np[2] == 9; }
 RT_DEV WaveLds* stage_tree(const DevTree& T, float4* s_nodes) {
     const bool compact = T.h16_np[0] > 0;
@@ -402,8 +403,13 @@ RT_DEV WaveLds* stage_tree(const DevTree& T, float4* s_nodes) {
     } else {
         for (int t = threadIdx.x; t < T.n_nodes * 3; t += 256) s_nodes[t] = T.nodes4[t];
     }
+    // behind that (trees with a plane table): the planes themselves, rounded to binary16 once — closest_tree forms every ray's quotients from them
+    if (compact) {
+        float* s_pl = (float*)(s_nodes + T.n_nodes * (regular_planes(T) ? 2 : 1));
+        for (int t = threadIdx.x; t < T.h16_np[0] + T.h16_np[1] + T.h16_np[2]; t += 256) s_pl[t] = fl(rf(T.h16_planes[t]));
+    }
     __syncthreads();
-    return (WaveLds*)(s_nodes + T.n_nodes * (compact ? (regular_planes(T) ? 2 : 1) : 3)) + (threadIdx.x >> 6);
+    return (WaveLds*)(s_nodes + T.n_nodes * (compact ? (regular_planes(T) ? 2 : 1) : 3) + (compact ? kPlaneLds4 : 0)) + (threadIdx.x >> 6);
 }
 
 // intersect_ray_aabb for the EIGHT children of a node at once (regular trees: a child box is a half of the parent's on every axis,
@@ -466,15 +472,15 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
         L.key[lane] = (unsigned long long)closest.bits << 32;
         if (np0 > 0) {
             // the ray's parameter at every box plane: the quotients intersect_ray_aabb forms, one division per plane
-            const float* __restrict__ pl = T.h16_planes;
+            const float* pl = (const float*)(s_nodes + n_nodes * (regular ? 2 : 1));       // (LDS: rf(plane) as a float, stage_tree)
             // (nine quotients per divisor: div_by — the compiler's IEEE division without its scaling steps and with the refined
             // reciprocal shared; bit-identical for every pair of binary16 operands, tools/micro/div_shared.hip)
             { const DivBy D = div_prepare(fl(r.d.x));
-_Pragma("unroll 1") for (int k = 0; k < np0; ++k) tp[k] = rf(div_by(fl(rf(pl[k]) - r.o.x), D)).bits; }
+_Pragma("unroll 1") for (int k = 0; k < np0; ++k) tp[k] = rf(div_by(fl(rf(pl[k] - fl(r.o.x))), D)).bits; }
             { const DivBy D = div_prepare(fl(r.d.y));
-_Pragma("unroll 1") for (int k = 0; k < np1; ++k) tp[np0 + k] = rf(div_by(fl(rf(pl[np0 + k]) - r.o.y), D)).bits; }
+_Pragma("unroll 1") for (int k = 0; k < np1; ++k) tp[np0 + k] = rf(div_by(fl(rf(pl[np0 + k] - fl(r.o.y))), D)).bits; }
             { const DivBy D = div_prepare(fl(r.d.z));
-_Pragma("unroll 1") for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = rf(div_by(fl(rf(pl[np0 + np1 + k]) - r.o.z), D)).bits; }
+_Pragma("unroll 1") for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = rf(div_by(fl(rf(pl[np0 + np1 + k] - fl(r.o.z))), D)).bits; }
         }
         wave_sync();
         // ---- phase 1: walk; every visited non-empty level-3 node becomes a segment of one of the pools (or stalls the lane when that
@@ -1012,7 +1018,7 @@ const char* render_kernel_name_h(bool tree, int mode) {
 // LDS of a block of the binary16 tree kernels: the nodes (stage_tree), then one WaveLds per wave
 static size_t h16_lds_bytes(bool tree, const DevTree& T) {
     const bool regular = T.h16_np[0] == 9 && T.h16_np[1] == 9 && T.h16_np[2] == 9;
-    return tree ? (size_t)T.n_nodes * (T.h16_np[0] > 0 ? (regular ? 2 : 1) * sizeof(float4) : sizeof(DevNode)) + 4 * sizeof(h16::WaveLds) : 0;
+    return tree ? (size_t)T.n_nodes * (T.h16_np[0] > 0 ? (regular ? 2 : 1) * sizeof(float4) : sizeof(DevNode)) + (T.h16_np[0] > 0 ? h16::kPlaneLds4 * sizeof(float4) : 0) + 4 * sizeof(h16::WaveLds) : 0;
 }
 
 hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum, int solo_sum);   // rt_kernels.hip
