@@ -854,6 +854,26 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
 // rays — the wave does not wait for its longest walk.  `closest`/`best` persist with the caller.
 // COOPG selects the walk: 4 = walk_pool (sparse grids), 5 = the same walk, the pre-classified chains start alone in their waves (very sparse grids), 2 = walk_pool_dense, 1 = none — trees without a candidate grid (and the
 // reference traversal mode) take the literal scan for every ray.
+// The spheres every bounce of every ray meets before its walk — the ground sphere and the first kHotLarge of the grid's large spheres
+// (geometry and brick) — are staged in LDS behind the waves' pools by the kernels with a pooled walk: as uniform global loads in the
+// serial part of a bounce each cost a full cache round trip (C2 / C3 are as long as their longest pixel: a lone bounce is what counts).
+constexpr int kHotLarge = 8;
+constexpr int kHotSlots = 1 + 3 * kHotLarge;                   // float4 slots: ground | large_hot[k] | large_brick[2k], [2k + 1]
+RT_DEV float4* hot_spheres(const float4* s_nodes, int n_nodes) { return (float4*)((WalkLds*)(s_nodes + n_nodes * 3) + 4); }
+template <bool POOL>
+RT_DEV void stage_tree_fp32(const DevScene& S, const DevTree& T, float4* s_nodes) {
+    const int n4 = T.n_nodes * 3;
+    for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = T.nodes4[t];
+    if (POOL) {
+        float4* h = hot_spheres(s_nodes, T.n_nodes);
+        const int nl = min(T.acc.n_large, kHotLarge);
+        if (threadIdx.x == 0) h[0] = S.ground_valid ? S.list_hot[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)threadIdx.x < nl) h[1 + threadIdx.x] = T.acc.large_hot[threadIdx.x];
+        if ((int)threadIdx.x < 2 * nl) h[1 + kHotLarge + threadIdx.x] = T.acc.large_brick[threadIdx.x];
+    }
+    __syncthreads();
+}
+
 struct TreeState { Walk W; float g_t; int g_id; bool tie, pending; };
 RT_DEV void tree_state_init(TreeState& ts) {
     ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1;
@@ -867,7 +887,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     if (fresh) { closest = FLT_MAX; best = -1; }
     if (S.ground_valid && fresh) {
         WPASS(WP_GROUND);
-        const float4 g = S.list_hot[0];
+        const float4 g = COOPG != 1 ? hot_spheres(s_nodes, T.n_nodes)[0] : S.list_hot[0];
         int gb = -1;
         // origin outside the sphere (c > 0) and heading away from its centre (b > 0): disc <= fl(b*b), so sqrt(disc) <= b and
         // both roots are <= 0 — the float test cannot pass (no margin involved); saves the exact sqrt and two divisions
@@ -893,7 +913,8 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             const float ra = __builtin_amdgcn_rcpf(a);
             for (int k = 0; k < T.acc.n_large; ++k) {
                 // same cheap pre-filter as in the walk: exact roots only for a sphere that can still win
-                const float4 sp = T.acc.large_hot[k];
+                const float4* hs = hot_spheres(s_nodes, T.n_nodes);
+                const float4 sp = k < kHotLarge ? hs[1 + k] : T.acc.large_hot[k];
                 WPASS(WP_LARGE_K);
                 const float ocx = r.o.x - sp.x, ocy = r.o.y - sp.y, ocz = r.o.z - sp.z;
                 const float b = ocx * r.d.x + ocy * r.d.y + ocz * r.d.z;
@@ -911,7 +932,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
                         const float t1 = (-b - sq) / a;
                         if (t1 > 0.001f) cand = t1;
                         else { const float t2 = (-b + sq) / a; if (t2 > 0.001f) cand = t2; }
-                        offer(T, s_nodes, r, cand, T.acc.large_brick[2 * k], T.acc.large_brick[2 * k + 1], closest, best, ts.tie STAT_PASS);
+                        offer(T, s_nodes, r, cand, k < kHotLarge ? hs[1 + kHotLarge + 2 * k] : T.acc.large_brick[2 * k], k < kHotLarge ? hs[2 + kHotLarge + 2 * k] : T.acc.large_brick[2 * k + 1], closest, best, ts.tie STAT_PASS);
                     }
                 }
             }
@@ -1102,11 +1123,7 @@ __global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, 
 template <bool TREE, int MODE, int COOPG>
 __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     extern __shared__ float4 s_nodes[];
-    if (TREE) {
-        const int n4 = A.tree.n_nodes * 3;
-        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
-        __syncthreads();
-    }
+    if (TREE) stage_tree_fp32<COOPG != 1>(A.scene, A.tree, s_nodes);
     const int lane = threadIdx.x & 63;
     const long long n_slots = A.n_local_tiles * 64;
     const int ns = (MODE == 0) ? A.ns : 1;
@@ -1402,11 +1419,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 template <bool TREE, int COOPG = 1>
 __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ pilot) {
     extern __shared__ float4 s_nodes[];
-    if (TREE) {
-        const int n4 = A.tree.n_nodes * 3;
-        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = A.tree.nodes4[t];
-        __syncthreads();
-    }
+    if (TREE) stage_tree_fp32<COOPG != 1>(A.scene, A.tree, s_nodes);
     const int lane = threadIdx.x & 63;
     // quarter resolution: one pilot pixel per 2x2 block (long chains cluster), its RT_PILOT_SAMPLES samples in adjacent
     // lanes (the pass is as long as its longest serial chain); a wave covers 4 / RT_PILOT_SAMPLES tiles
@@ -1548,11 +1561,7 @@ template <bool TREE, int COOPG = 1>
 __global__ __launch_bounds__(256) void k_trace(RenderArgs A, const float* rays, long long n, rt_hit_record* out) {
     const DevScene& S = A.scene; const DevTree& T = A.tree;
     extern __shared__ float4 s_nodes[];
-    if (TREE) {
-        const int n4 = T.n_nodes * 3;
-        for (int t = threadIdx.x; t < n4; t += 256) s_nodes[t] = T.nodes4[t];
-        __syncthreads();
-    }
+    if (TREE) stage_tree_fp32<COOPG != 1>(S, T, s_nodes);
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = gid < n;
     RayF r; r.o = {0.f, 0.f, 0.f}; r.d = {0.f, 1.f, 0.f};
@@ -1619,7 +1628,7 @@ hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part,
 #endif
 
 // LDS of a block of the tree kernels: the nodes, then one WalkLds per wave
-static size_t tree_lds_bytes(int n_nodes, bool pool = false) { return (size_t)n_nodes * sizeof(DevNode) + (pool ? 4 * sizeof(WalkLds) : 0); }
+static size_t tree_lds_bytes(int n_nodes, bool pool = false) { return (size_t)n_nodes * sizeof(DevNode) + (pool ? 4 * sizeof(WalkLds) + kHotSlots * sizeof(float4) : 0); }
 
 // blocks the chip holds at once for one render kernel variant (occupancy query, cached); the persistent grid is never
 // larger than that, and never larger than the work
