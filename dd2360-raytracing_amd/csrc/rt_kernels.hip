@@ -480,6 +480,9 @@ RT_DEV void pool_candidate(const DevTree& T, const float4* s_nodes, WalkLds& L, 
     const DevAccel& A = T.acc;
     const int owner = (int)c.w, e = (int)c.z;
     const float b = __uint_as_float(c.x), disc = __uint_as_float(c.y);
+    // (the brick is asked for before the roots are formed: its round trip overlaps the square root and the divisions — a candidate that
+    // cannot win has fetched it for nothing, a chain alone in its wave has one dependent round trip less per candidate)
+    const float4 blo = A.brick[2 * e], bhi = A.brick[2 * e + 1];
     const float4 r0 = L.ray[2 * owner], r1 = L.ray[2 * owner + 1];
     RayF q; q.o = {r0.x, r0.y, r0.z}; q.d = {r0.w, r1.x, r1.y};
     const float a = r1.z;
@@ -492,7 +495,6 @@ RT_DEV void pool_candidate(const DevTree& T, const float4* s_nodes, WalkLds& L, 
     if (t1 > 0.001f) cand = t1;
     else { const float t2 = (-b + sq) / a; if (t2 > 0.001f) cand = t2; }
     if (!(cand <= best_t)) return;
-    const float4 blo = A.brick[2 * e], bhi = A.brick[2 * e + 1];
     const int id = __float_as_int(blo.w);
     STAT(st, ST_OFFERS, 1);
     bool tie = false;
