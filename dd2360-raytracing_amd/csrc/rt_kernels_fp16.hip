@@ -445,7 +445,7 @@ RT_DEV unsigned expand_node(const unsigned short* tp, uint32_t w) {
     return mask;
 }
 
-RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, WaveLds& L, const Ray& r, R a, bool live, R& closest, int& best) {
+RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_nodes, WaveLds& L, Ray& r, R& a, bool live, R& closest, int& best) {
     // the packed pairs (rt_api.hip, octree_upload) through a buffer descriptor: one offset register and immediate offsets serve the
     // kPP loads of a pass, and a pass may read past the last pair of the array (such loads return zeros; their results are masked)
     const __amdgpu_buffer_rsrc_t ent = __builtin_amdgcn_make_buffer_rsrc((void*)T.ent_hot, 0, T.n_entries * 8, 0x00020000);
@@ -654,7 +654,13 @@ _Pragma("unroll 1") for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = rf(div_by(
         }
         drain_candidates(L, ent, lane, qn);
         H16_ADD(2, tph);                                             // tests
-        // ---- phase 3
+        // ---- phase 3.  (The ray comes back from where phase 2 put it for the other lanes: between that store and this load its seven
+        // values need no registers — the test loop spills otherwise — and the bits are the same.)
+        {
+            const uint4 q0 = L.u.p2.ray[2 * lane]; const uint2 q1 = *(const uint2*)&L.u.p2.ray[2 * lane + 1]; const unsigned qa = L.u.p2.ray[2 * lane + 1].z;
+            r.o.x.bits = (uint16_t)q0.x; r.o.y.bits = (uint16_t)q0.y; r.o.z.bits = (uint16_t)q0.z; r.d.x.bits = (uint16_t)q0.w;
+            r.d.y.bits = (uint16_t)q1.x; r.d.z.bits = (uint16_t)q1.y; a.bits = (uint16_t)qa;
+        }
         const unsigned long long k = L.key[lane];
         closest.bits = (uint16_t)(k >> 32);
         if ((uint32_t)k != 0u) e_best = (int)(uint32_t)k - 1;
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
         }
         if (!thin && !live && !retired && ns > 0) { slot = first_free + (long long)atomicAdd(A.queue, 1u); begin_pixel(); }
         if (__ballot(live) == 0ull) break;
-        const R a = vdot(r.d, r.d);
+        R a = vdot(r.d, r.d);
         R closest = rf(FLT_MAX); int best = -1;                              // real_t(FLT_MAX) = +inf in binary16
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, *wl, r, a, live, closest, best);
         else closest_list(A.scene, r, a, closest, best);
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_tile_cost_h(RenderArgs
     if (live) r = primary_ray(cam, i, j, A.max_x, A.max_y, ps);
     int bounces = 0;
     while (__ballot(live) != 0ull) {
-        const R a = vdot(r.d, r.d);
+        R a = vdot(r.d, r.d);
         R closest = rf(FLT_MAX); int best = -1;
         if (TREE) closest_tree(A.scene, A.tree, s_nodes, *wl, r, a, live, closest, best);
         else closest_list(A.scene, r, a, closest, best);
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(256) void k_trace_h(DevScene S, DevTree T, const fl
     const bool live = gid < n;
     Ray r; r.o = {ri(0), ri(0), ri(0)}; r.d = {ri(0), ri(1), ri(0)};
     if (live) { const float* p = rays + gid * 6; r.o = vload(p); r.d = vload(p + 3); }
-    const R a = vdot(r.d, r.d);
+    R a = vdot(r.d, r.d);
     R closest = rf(FLT_MAX); int best = -1;
     if (TREE) closest_tree(S, T, s_nodes, *wl, r, a, live, closest, best);
     else closest_list(S, r, a, closest, best);

@@ -100,7 +100,7 @@
 #define RT_H16_SMALL 256        // small segments per round (C4: the 56 upper cells that hold one large sphere each)
 #endif
 #ifndef RT_H16_PP
-#define RT_H16_PP 8             // pairs per lane and pass of the big segments' test loop (at most 16: pass_mask).  C4, round 3: 4: 38.3 ms, 6: 37.9, 8: 37.05 (round 2, with the b and disc words kept for the queue: 2: 52.7, 3: 48.3, 4: 46.0)
+#define RT_H16_PP 10            // pairs per lane and pass of the big segments' test loop (at most 16: pass_mask).  C4, round 3: 4: 38.3 ms, 6: 37.9, 8: 37.05; with the ray out of the registers during the tests (closest_tree, phase 3): 8: 35.6, 10: 35.1, 12: 35.4
 #endif
 #ifndef RT_H16_LONG_PER_WAVE
 #define RT_H16_LONG_PER_WAVE 16 // pre-classified chains per thin wave.  C4 (round 2): 4: 56.7 ms, 8: 57.3, 16: 57.1, 32: 61.5
