@@ -12,6 +12,7 @@
 #include "rt_device.h"
 #include "rt_real.h"
 #include "rt_tuning.h"
+#include "rt_divshared.h"
 
 #pragma clang fp contract(off)
 
@@ -328,24 +329,8 @@ RT_DEV void push_pass(WaveLds& L, const __amdgpu_buffer_rsrc_t ent, int lane, ui
     }
 }
 
-// float division by a divisor that serves several quotients.  The compiler's IEEE division is v_div_scale_f32 x 2, v_rcp_f32, two
-// multiply-adds refining the reciprocal, five forming the quotient, v_div_fmas_f32, v_div_fixup_f32; for operands that came from
-// binary16 (magnitudes in [2^-24, 65504], or 0 / inf / NaN) the scale factors are always 1, so the scaling drops out and the refined
-// reciprocal can be shared: the same multiply-adds on the same values.  tools/micro/div_shared.hip compares the two forms for all
-// 2^32 pairs of binary16 operands on the GPU: no quotient differs, in float or rounded to binary16.
-struct DivBy { float d, r; };
-RT_DEV DivBy div_prepare(float d) {
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r0, 1.0f);
-    return {d, __builtin_fmaf(e, r0, r0)};
-}
-RT_DEV float div_by(float n, const DivBy& D) {
-    float q = n * D.r;
-    float rem = __builtin_fmaf(-D.d, q, n);
-    q = __builtin_fmaf(rem, D.r, q);
-    rem = __builtin_fmaf(-D.d, q, n);
-    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(rem, D.r, q), D.d, n);
-}
+// div_prepare / div_by (rt_divshared.h): IEEE float division with the refined reciprocal shared per divisor — the header is also what
+// tools/micro/div_shared.hip checks for all 2^32 pairs of binary16 operands.
 
 // intersect_ray_aabb (acceleration_structure.h:226-244) with the six quotients looked up in the lane's plane table
 RT_DEV bool ray_box_tab(const unsigned short* tp, uint32_t w) {

@@ -8,19 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-struct DivBy { float d, r; };
-__device__ __forceinline__ DivBy div_prepare(float d) {
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r0, 1.0f);
-    return {d, __builtin_fmaf(e, r0, r0)};
-}
-__device__ __forceinline__ float div_by(float n, const DivBy& D) {
-    float q = n * D.r;
-    float rem = __builtin_fmaf(-D.d, q, n);
-    q = __builtin_fmaf(rem, D.r, q);
-    rem = __builtin_fmaf(-D.d, q, n);
-    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(rem, D.r, q), D.d, n);
-}
+#include "../../dd2360-raytracing_amd/csrc/rt_divshared.h"      // the kernels' own div_prepare / div_by — not a copy
+using rt::DivBy; using rt::div_prepare; using rt::div_by;
 __device__ __forceinline__ float h2f(uint32_t bits) { _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)bits); return (float)h; }
 __global__ void k(unsigned long long* bad, unsigned long long* bad16, uint32_t* first) {
     const uint32_t db = blockIdx.x;                               // divisor: every binary16 bit pattern

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dd2360-raytracing_amd"))
 import numpy as np, torch
 import rt_amd as rt
-rt.LIB_PATH = os.path.join(ROOT, "dd2360-raytracing_amd", "librt_amd_stats.so")
+rt.LIB_PATH = os.environ.get("RT_STATS_LIB", os.path.join(ROOT, "dd2360-raytracing_amd", "librt_amd_stats.so"))
 L = rt.lib()
 nparts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
