@@ -10,8 +10,11 @@
 #include <new>
 #include <limits>
 #include <algorithm>
+#include <mutex>
+#include <cstdlib>
 #include "rt_handles.h"
 #include "rt_octgeom.h"
+#include "../host/rt_image.hpp"
 
 namespace rt {
 hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
@@ -243,7 +246,8 @@ static int ctx_reserve(rt_render_ctx& C, int64_t tiles) {
     int rc = free_all(old, 4);
     if (rc) return rc;
     void* nw[4] = {nullptr, nullptr, nullptr, nullptr};
-    const size_t bytes[4] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 80, sizeof(unsigned int) * (size_t)tiles * 64};
+    // (flags: 64 + 16 + 16 bytes per tile; long chains: 64 entries per tile, then the tail list: 16 per tile — at most a quarter of the tiles)
+    const size_t bytes[4] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 96, sizeof(unsigned int) * (size_t)tiles * 80};
     for (int k = 0; k < 4; ++k) {
         const hipError_t e = hipMalloc(&nw[k], bytes[k]);
         if (e != hipSuccess) { (void)free_all(nw, 4); return (int)e; }
@@ -685,6 +689,17 @@ static DevTree tree_args(const rt_octree* d_octree) {
     else memset(&T, 0, sizeof(T));
     return T;
 }
+// a scheduling knob of rt_tuning.h, overridable from the environment for tuning sweeps on one build (read once per process and knob)
+static float tune_value(const char* env, float dflt) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::string, float>> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& kv : seen) if (kv.first == env) return kv.second;
+    float v = dflt;
+    if (const char* e = getenv(env)) { char* end = nullptr; const float x = strtof(e, &end); if (end != e) v = x; }
+    seen.emplace_back(env, v);
+    return v;
+}
 static bool capturing(hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -712,6 +727,8 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     A.scene = world->z->dev;
     A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
+    A.tail_list = nullptr; A.f_tail = 0.f;
+    A.n_lanes = 0; A.f_inflight = tune_value("RT_F_INFLIGHT", RT_F_INFLIGHT); A.f_static = tune_value("RT_F_STATIC", RT_F_STATIC);
     const bool sched = mode == 0 && ns >= 4;
     // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame: call rt_render
     // (or rt_render_ctx_reserve) once before capturing it into a hipGraph.
@@ -724,7 +741,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     if (!cap && C.has_done && C.last_stream != st) RT_TRY(hipStreamWaitEvent(st, C.done, 0));
     A.queue = C.d_queue + (size_t)(C.launches++ % kQueueSlots) * kQueueStride;
     C.last_queue = A.queue;
-    RT_TRY(launch_zero_counters(A.queue, 6, st));
+    RT_TRY(launch_zero_counters(A.queue, (int)kQueueStride, st));
     if (mode == 1) {
         // render_progressive is one sample per launch (main.cu:119-142, called once per displayed frame, :275).  The pass with
         // current_sample == 1 runs the pilot pass of rt_render and KEEPS the tile order (most expensive tiles first) in the context;
@@ -744,6 +761,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     }
     if (sched) {
         const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long
+        if (classify && world->precision != RT_PRECISION_FP16) { A.tail_list = C.d_long + (size_t)A.n_local_tiles * 64; A.f_tail = tune_value("RT_F_TAIL", RT_F_TAIL); }
         if (world->precision == RT_PRECISION_FP16) RT_TRY(launch_tile_order_h(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
         else RT_TRY(launch_tile_order(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
         A.order = C.d_order;
@@ -866,27 +884,8 @@ int rt_debug_pilot(int* out, int n) { return (int)read_pilot_dbg(out, n); }
 #endif
 
 // ------------------------------------------------------------------------------------------------ output
-static float channel(const void* fb, size_t k, int precision) {
-    if (precision == RT_PRECISION_FP16) return half_bits_to_float(((const uint16_t*)fb)[k]);
-    return ((const float*)fb)[k];
-}
-
-// output_to_stream (main.cu:321-333) into a string: the one formatter behind rt_format_ppm and rt_write_ppm
-static void ppm_text(int nx, int ny, const void* fb, int precision, std::string& s) {
-    s.reserve((size_t)nx * ny * 12 + 32);
-    s += "P3\n"; s += std::to_string(nx); s += ' '; s += std::to_string(ny); s += "\n255\n";
-    char line[48];
-    for (int j = ny - 1; j >= 0; j--) {
-        for (int i = 0; i < nx; i++) {
-            const size_t pixel_index = (size_t)j * nx + i;
-            const int ir = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 0, precision));
-            const int ig = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 1, precision));
-            const int ib = static_cast<int>(255.99 * channel(fb, pixel_index * 3 + 2, precision));
-            const int len = snprintf(line, sizeof(line), "%d %d %d\n", ir, ig, ib);
-            s.append(line, (size_t)len);
-        }
-    }
-}
+// the formatters live in host/rt_image.hpp (host-only C++: also compiled under ASan / UBSan by tests/test_host_sanitizers.py)
+using rt::ppm_text;
 
 int64_t rt_format_ppm(int nx, int ny, const void* fb, int precision, char* out, int64_t cap) {
     if (nx <= 0 || ny <= 0 || !fb) return RT_EINVAL;
@@ -916,24 +915,7 @@ int rt_write_image(const char* path, int nx, int ny, const void* fb, int precisi
     if (!f) return RT_EIO;
     bool ok = true;
     try {
-        if (format == RT_IMAGE_P6) {
-            ok = fprintf(f, "P6\n%d %d\n255\n", nx, ny) > 0;
-            std::vector<unsigned char> row((size_t)nx * 3);
-            for (int j = ny - 1; j >= 0 && ok; j--) {
-                for (int i = 0; i < nx * 3; i++) {
-                    const int v = static_cast<int>(255.99 * channel(fb, (size_t)j * nx * 3 + i, precision));
-                    row[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
-                }
-                ok = fwrite(row.data(), 1, row.size(), f) == row.size();
-            }
-        } else {
-            ok = fprintf(f, "PF\n%d %d\n-1.0\n", nx, ny) > 0;
-            std::vector<float> row((size_t)nx * 3);
-            for (int j = 0; j < ny && ok; j++) {
-                for (int i = 0; i < nx * 3; i++) row[i] = channel(fb, (size_t)j * nx * 3 + i, precision);
-                ok = fwrite(row.data(), sizeof(float), row.size(), f) == row.size();
-            }
-        }
+        ok = rt::write_binary_image(f, nx, ny, fb, precision, format);
     } catch (const std::bad_alloc&) { fclose(f); return RT_ENOMEM; }
     if (fclose(f) != 0) ok = false;
     return ok ? 0 : RT_EIO;

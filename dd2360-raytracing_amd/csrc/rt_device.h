@@ -111,6 +111,7 @@ struct DevTree {
     DevAccel acc;
 };
 
+constexpr int kQueueThr = 32;
 struct RenderArgs {
     void* fb;
     rt_rand_state* rand_state;
@@ -119,6 +120,14 @@ struct RenderArgs {
     int32_t part, nparts;
     int64_t n_local_tiles;
     unsigned int* queue;                  // counters of this launch, zeroed on the stream: [0] work counter [1] thin waves [2] long chains [3] long head
+                                          // [4] solo chains [5] solo head; in the slot's second 128-byte line, written by k_tile_order before the render kernel starts and
+                                          // only read by it (the first line is hammered by every wave's atomics: a load from it waits behind them):
+                                          // [kQueueThr] in-flight chain threshold (iterations; 0 = the rate rule only) [kQueueThr + 1] pilot-sum threshold
+                                          // [kQueueThr + 2] first slot of the queue's tail + 1 (0 = no tail): those slots go through tail_list
+    int32_t n_lanes;                      // lanes of the persistent render grid this launch will run on (64 x waves): the per-lane load is the yardstick of a "long" pixel
+    const unsigned int* tail_list;        // the pixels of the last tiles of the hand-out order, most expensive 2x2 block first (k_tail_order); NULL = none
+    float f_tail;                         // share of the launch's predicted work handed out per pixel instead of per tile, at the end of the queue
+    float f_inflight, f_static;           // a pixel is long when its predicted chain exceeds f x (predicted iterations of the launch / n_lanes): found in flight / by the pilot
     const unsigned int* order;            // hand-out order of the local tiles (most expensive first), or NULL = identity
     const unsigned char* long_flag;       // per local pixel (local_tile*64 + l): pre-classified long chain, or NULL
     const unsigned int* long_list;        // the pre-classified long chains (queue[2] = count, queue[3] = next to hand out)

@@ -19,7 +19,7 @@ struct rt_octree;
 // call's stream waits for before it touches the workspace), so two streams sharing a context serialise instead of racing;
 // give concurrent frames a context each (rt_render_ctx_create).
 struct rt_render_ctx {
-    // work counters of the persistent render kernel: a ring of slots (one per launch, 64 B apart), zeroed on the stream
+    // work counters of the persistent render kernel: a ring of slots (one per launch, 256 B apart), zeroed on the stream
     unsigned int* d_queue = nullptr; unsigned launches = 0;
     // scheduling workspace (tile costs, hand-out order, long-chain flags and list), grown on demand
     int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
@@ -32,7 +32,7 @@ struct rt_render_ctx {
     // ordering of successive launches that share this context
     hipEvent_t done = nullptr; hipStream_t last_stream = nullptr; bool has_done = false;
 };
-static const unsigned kQueueSlots = 64, kQueueStride = 16;
+static const unsigned kQueueSlots = 64, kQueueStride = 64;     // 256 bytes per launch: counters in the first 128-byte line, read-only thresholds in the second (rt_device.h)
 
 uint64_t rt_next_serial();                  // handles are numbered: a new handle at a recycled address is not mistaken for the old one
 

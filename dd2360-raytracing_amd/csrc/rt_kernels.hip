@@ -10,9 +10,10 @@
 //     queue (one pixel position of 64 different tiles per wave: long chains cluster), most expensive tiles first;
 //   * the reference's `for sample { for bounce {..} }` nest is flattened into ONE loop per lane: a lane whose path
 //     ended starts its next sample at once instead of idling until the slowest path of the wave finishes;
-//   * octree on: candidates come from an exact culling grid (rt_accel.h), the reference's traversal is the fallback; on sparse
-//     grids the wave's sphere tests are pooled and dealt out evenly over its 64 lanes (walk_pool), on dense ones every lane
-//     walks its own columns (walk_lanes); waves holding long pixel chains stop refilling ("thin");
+//   * octree on: candidates come from an exact culling grid (rt_accel.h), the reference's traversal is the fallback; a wave's
+//     sphere tests are pooled and dealt out evenly over its 64 lanes — walk_pool on sparse grids (two columns per ray and round),
+//     walk_pool_dense on dense ones (one column, four entries per lane and pass, the owner's best hit re-read every pass);
+//     waves holding long pixel chains stop refilling ("thin");
 //   * no virtual calls, no device heap, no recursion: materials are a tag + 4 floats, the octree is a pre-order
 //     node array with skip links staged in LDS, bucket contents are pre-gathered (centre, r^2) float4 streams;
 //   * hitable_list path: the sphere index is wave-uniform, so sphere data comes through scalar loads (SGPR operands).
@@ -1145,6 +1146,9 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     const unsigned int n_long_raw = A.long_list ? A.queue[2] : 0u, n_solo_raw = A.long_list ? A.queue[4] : 0u;
     const bool use_long = (n_long_raw + n_solo_raw) != 0u && (long long)(n_long_raw + n_solo_raw) * 64 <= n_slots;
     const unsigned int n_long = use_long ? n_long_raw : 0u, n_solo = use_long ? n_solo_raw : 0u;
+#ifdef RT_THR_HOIST
+    const unsigned int long_thr_k = MODE == 0 ? A.queue[kQueueThr] : 0u;
+#endif
     bool solo = false, solo_done = false;      // this wave started with one of the longest chains, alone (lane 0); that list is exhausted
     Rng s = {0, 0, 0, 0, 0, 0};
     V3 col = {0.0f, 0.0f, 0.0f};
@@ -1181,12 +1185,21 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         while (slot < n_slots) {
             // Slots are interleaved over blocks of 64 tiles (in hand-out order): consecutive slots are the same pixel
             // position of 64 different tiles, so the pixels of one tile (long chains cluster) never travel together.
-            const long long blk = slot >> 12;
-            const long long tiles_in_blk = (A.n_local_tiles - blk * 64) < 64 ? (A.n_local_tiles - blk * 64) : 64;
-            const long long within = slot & 4095;
-            const long long rank = blk * 64 + within % tiles_in_blk;          // position in the hand-out order
-            const int l = (int)(within / tiles_in_blk);
-            const long long local_tile = A.order ? (long long)A.order[rank] : rank;
+            // The END of the queue is handed out per pixel, most expensive 2x2 pilot block first (k_tail_order): a launch with few pixels
+            // per lane ends when its last-started pixels do, and inside a tile of a cheap class sit pixels of three times its mean.
+            long long local_tile; int l;
+            const long long tail0 = (MODE == 0 && A.tail_list) ? (long long)A.queue[kQueueThr + 2] : 0;
+            if (tail0 > 0 && slot >= tail0 - 1) {
+                const unsigned int pid = A.tail_list[slot - (tail0 - 1)];
+                local_tile = (long long)(pid >> 6); l = (int)(pid & 63u);
+            } else {
+                const long long blk = slot >> 12;
+                const long long tiles_in_blk = (A.n_local_tiles - blk * 64) < 64 ? (A.n_local_tiles - blk * 64) : 64;
+                const long long within = slot & 4095;
+                const long long rank = blk * 64 + within % tiles_in_blk;          // position in the hand-out order
+                l = (int)(within / tiles_in_blk);
+                local_tile = A.order ? (long long)A.order[rank] : rank;
+            }
             const long long tile = part_tile(local_tile, A.part, A.nparts);
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
@@ -1362,7 +1375,19 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                 if (sample < ns) {
                     { const RenderArgs& C = *cold_args(); r = primary_ray(C.scene.cam, i, j, C.max_x, C.max_y, s); }
                     // classify after every 4th sample while enough of the chain is left for it to matter
-                    if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns && iters >= (unsigned int)((COOPG == 2 ? RT_LONG_RATE_DENSE : RT_LONG_RATE) * sample)) {
+                    // ... long from RT_LONG_RATE bounces per sample on, or — k_tile_order — when the chain this rate predicts (rate x ns) is a sizeable
+                    // part of what ONE lane works through in this launch (queue[kQueueThr]; 0 when no scheduling pass ran)
+                    bool now_long = false;
+                    if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns) {
+#ifdef RT_THR_HOIST
+                        const unsigned int long_thr = long_thr_k;
+#else
+                        const unsigned int long_thr = MODE == 0 ? cold_args()->queue[kQueueThr] : 0u;
+#endif
+                        now_long = iters >= (unsigned int)((COOPG == 2 ? RT_LONG_RATE_DENSE : RT_LONG_RATE) * sample) ||
+                                   (long_thr != 0u && (unsigned long long)iters * (unsigned int)ns >= (unsigned long long)long_thr * (unsigned int)sample);
+                    }
+                    if (now_long) {
                         RT_STATS_ONLY(
                         if (!is_long) ++dbg_long;
                         )
@@ -1479,7 +1504,7 @@ RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (
 // one thread per 2x2 block: the pilot counts of the block and its eight neighbours decide whether its pixels start as long chains.
 // A neighbour outside the frame, or in a tile of another part of a partitioned frame, counts as the block itself.
 __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigned char* __restrict__ pilot, unsigned char* __restrict__ long_flag,
-                                                    unsigned int* __restrict__ long_list, int long_sum, int solo_sum) {
+                                                    unsigned int* __restrict__ long_list, int long_sum, int solo_sum, unsigned char* __restrict__ sum8) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= A.n_local_tiles * 16) return;
     const long long local_tile = g >> 4;
@@ -1502,7 +1527,10 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
             }
             sum += v;
         }
-    const bool is_long = sum >= long_sum;
+    if (sum8) sum8[g] = (unsigned char)(sum < 255 ? sum : 255);                    // for k_tail_order
+    // (k_tile_order, which runs first, may have lowered the threshold: a chain is long relative to the launch's load per lane)
+    const int abs_sum = (int)A.queue[kQueueThr + 1];
+    const bool is_long = sum >= (abs_sum > 0 && abs_sum < long_sum ? abs_sum : long_sum);
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                          // the 2x2 block this pilot pixel stands for
@@ -1519,23 +1547,71 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
 }
 
 // one block of 16 waves: stable counting sort of the tiles by cost class, descending (each wave takes a contiguous chunk)
-__global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n) {
+//
+// It also sets the launch's yardstick for "long": the pilot's bounce counts predict the launch's iterations (a tile's cost is 4 x
+// the bounces of its 32 pilot samples; 64 pixels x ns samples follow them), and iterations / lanes of the persistent grid is what
+// one lane will work through — the LOAD.  A pixel whose chain is a sizeable fraction of the load decides when the launch ends
+// unless it runs in a thin wave from early on; whether 3000 bounces are long depends on the launch (C5 whole frame: load 18 000;
+// one part of eight: 2 250).  queue[kQueueThr] = in-flight threshold in iterations, queue[kQueueThr + 1] = the same as a 3x3 pilot sum (18 samples).
+__global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n, unsigned int* __restrict__ queue,
+                                                    int ns, int n_lanes, float f_inflight, float f_static, float f_tail, long long tail_cap_tiles) {
     __shared__ int s_cnt[16][8];
+    __shared__ long long s_sum[16];
+    __shared__ long long s_ccost[16][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long per = ((n + 15) / 16 + 63) / 64 * 64;          // tiles per wave, a multiple of 64
     const long long lo = wave * per, hi = (lo + per < n) ? lo + per : n;
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long csum = 0;
+    long long ccost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (long long t = lo + lane; t < hi; t += 64) {
-        const int c = cost_class(cost[t]);
+        const int w = cost[t];
+        const int c = cost_class(w);
+        csum += w;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cnt[k] += (c == k) ? 1 : 0;
+        for (int k = 0; k < 8; ++k) { cnt[k] += (c == k) ? 1 : 0; ccost[k] += (c == k) ? w : 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        for (int off = 32; off > 0; off >>= 1) ccost[k] += __shfl_xor(ccost[k], off);
+        if (lane == 0) s_ccost[wave][k] = ccost[k];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         for (int off = 32; off > 0; off >>= 1) cnt[k] += __shfl_xor(cnt[k], off);
         if (lane == 0) s_cnt[wave][k] = cnt[k];
     }
+    for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+    if (lane == 0) s_sum[wave] = csum;
     __syncthreads();
+    if (threadIdx.x == 0 && queue && n_lanes > 0 && ns > 0) {       // (s_cnt / s_sum / s_ccost are complete: the barrier above)
+        long long tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_sum[w];
+        const double load = (double)tot * 0.5 * (double)ns / (double)n_lanes;          // predicted iterations per lane
+        // (floors: in a launch with a pixel or two per lane every pixel is "long" by this measure — a chain must also be long as chains go)
+        double ti = (double)f_inflight * load, tsum = 18.0 * (double)f_static * load / (double)ns;
+        if (ti < (double)RT_LONG_RATE_MIN * ns) ti = (double)RT_LONG_RATE_MIN * ns;
+        if (tsum < (double)RT_PILOT_LONG_SUM_MIN) tsum = (double)RT_PILOT_LONG_SUM_MIN;
+        // the tail of the queue: the last tiles of the order that hold f_tail of the predicted work (tiles of one class taken as alike),
+        // from a multiple of 64 on — their pixels are handed out by k_tail_order's list
+        unsigned int tail_mark = 0u;
+        if (f_tail > 0.f && tot > 0) {
+            const double want = (1.0 - (double)f_tail) * (double)tot;
+            double cum = 0.0; long long r0 = n;
+            long long start = 0;
+            for (int k = 7; k >= 0; --k) {
+                long long nk = 0, ck = 0;
+                for (int w = 0; w < 16; ++w) { nk += s_cnt[w][k]; ck += s_ccost[w][k]; }
+                if (nk > 0 && cum + (double)ck >= want) { r0 = start + (long long)((want - cum) / ((double)ck / (double)nk)); break; }
+                cum += (double)ck; start += nk;
+            }
+            r0 = (r0 / 64) * 64;
+            if (r0 < n && (n - r0) <= tail_cap_tiles) tail_mark = (unsigned int)(r0 * 64 + 1);
+        }
+        queue[kQueueThr + 2] = tail_mark;
+        queue[kQueueThr] = f_inflight > 0.f ? (unsigned int)(ti < 1.0 ? 1.0 : (ti > 4.0e9 ? 4.0e9 : ti)) : 0u;
+        queue[kQueueThr + 1] = f_static > 0.f ? (unsigned int)(tsum < 1.0 ? 1.0 : (tsum > 1.0e9 ? 1.0e9 : tsum)) : 0u;
+    }
     long long base[8];
     long long run = 0;
 #pragma unroll
@@ -1554,6 +1630,35 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
             if (c == k) order[base[k] + __popcll(m & lt)] = (unsigned int)t;
             base[k] += __popcll(m);
         }
+    }
+}
+
+// The pixels of the queue's tail (tiles of rank >= R0 in the hand-out order), sorted by the pilot's count for their 2x2 block and its
+// eight neighbours (k_long_select's sum8), most expensive first: one block, a counting sort over the 256 values.  Which lane renders a
+// pixel and when never changes the pixel; the order inside one value is left to the atomics.
+__global__ __launch_bounds__(1024) void k_tail_order(const unsigned int* __restrict__ order, const unsigned char* __restrict__ sum8, unsigned int* __restrict__ tail_list,
+                                                    long long n, const unsigned int* __restrict__ queue) {
+    __shared__ unsigned int s_bin[256];
+    const unsigned int mark = queue[kQueueThr + 2];
+    if (mark == 0u) return;
+    const long long r0 = (long long)(mark - 1u) / 64;
+    const long long n_blocks = (n - r0) * 16;                        // 2x2 blocks of the tail tiles
+    for (int k = threadIdx.x; k < 256; k += 1024) s_bin[k] = 0u;
+    __syncthreads();
+    for (long long b = threadIdx.x; b < n_blocks; b += 1024) {
+        const long long tile = (long long)order[r0 + (b >> 4)];
+        atomicAdd(&s_bin[255 - sum8[tile * 16 + (b & 15)]], 4u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned int run = 0u; for (int k = 0; k < 256; ++k) { const unsigned int c = s_bin[k]; s_bin[k] = run; run += c; } }
+    __syncthreads();
+    for (long long b = threadIdx.x; b < n_blocks; b += 1024) {
+        const long long tile = (long long)order[r0 + (b >> 4)];
+        const int sub = (int)(b & 15);
+        const unsigned int pos = atomicAdd(&s_bin[255 - sum8[tile * 16 + sub]], 4u);
+        const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tail_list[pos + q] = (unsigned int)(tile * 64 + (ly + (q >> 1)) * 8 + lx + (q & 1));
     }
 }
 #endif
@@ -1698,14 +1803,21 @@ const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
 // the per-block counts: the long-chain list (if asked for) and the hand-out order of the tiles
 // (long_sum: the 3x3 pilot sum from which a block's pixels start as long chains; 0 = this translation unit's RT_PILOT_LONG_SUM)
 hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum, int solo_sum) {
+    // (the order kernel first: it also derives the launch's thresholds for long chains, which the selection reads)
+    // flags: 64 bytes per local tile (one per pixel), 16 (the pilot's count per 2x2 block), 16 (that count summed over the block's 3x3 neighbourhood)
+    const bool tail = flags && A.tail_list && A.f_tail > 0.f;
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles, A.queue, (int)A.ns, (int)A.n_lanes, A.f_inflight, A.f_static,
+                       tail ? A.f_tail : 0.f, (long long)(A.n_local_tiles / 4));
     if (flags) {
         const unsigned char* pilot = flags + (size_t)A.n_local_tiles * 64;
-        hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, pilot, flags, long_list, long_sum > 0 ? long_sum : RT_PILOT_LONG_SUM, solo_sum);
+        unsigned char* sum8 = flags + (size_t)A.n_local_tiles * 80;
+        hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, pilot, flags, long_list, long_sum > 0 ? long_sum : RT_PILOT_LONG_SUM, solo_sum, sum8);
+        if (tail) hipLaunchKernelGGL(k_tail_order, dim3(1), dim3(1024), 0, st, (const unsigned int*)order, (const unsigned char*)sum8, (unsigned int*)A.tail_list, (long long)A.n_local_tiles, (const unsigned int*)A.queue);
     }
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles);
     return hipGetLastError();
 }
 
+static unsigned render_grid_blocks(const RenderArgs& A, int variant, int mode);
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const long long per_block = 4 * (64 / (16 * RT_PILOT_SAMPLES));       // a wave covers 4 / RT_PILOT_SAMPLES tiles
@@ -1715,17 +1827,20 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
     // (the pilot paths walk the grid like the render kernel's waves do, through the wave's pool)
     const int variant = render_variant(tree, 0, A.tree.acc);
+    RenderArgs B = A;
+    B.n_lanes = tree ? (int)render_grid_blocks(A, variant, 0) * 256 : 0;      // (list scans keep the rate rule alone)
     if (variant == 5) hipLaunchKernelGGL((k_tile_cost<true, 5>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
     else if (variant == 4) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
     else if (variant == 2) hipLaunchKernelGGL((k_tile_cost<true, 2>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
     else if (tree) hipLaunchKernelGGL((k_tile_cost<true, 1>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
     else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
     // (chains in waves of their own: the variant for very sparse grids)
-    return launch_select_and_order(A, cost, order, flags, long_list, st, 0, variant == 5 ? RT_PILOT_SOLO_SUM : 0x7fffffff);
+    return launch_select_and_order(B, cost, order, flags, long_list, st, 0, variant == 5 ? RT_PILOT_SOLO_SUM : 0x7fffffff);
 }
 
+// blocks of the persistent grid of k_render<true, MODE, COOPG> for this launch: what the chip holds, never more than the work
 template <int MODE, int COOPG>
-static hipError_t launch_render_tree(const RenderArgs& A, size_t lds, hipStream_t st) {
+static unsigned tree_grid_blocks(const RenderArgs& A, size_t lds) {
     const unsigned need = (unsigned)((A.n_local_tiles + 3) / 4);
     // the occupancy query costs as much host time as the launch: remembered per thread for the last (device, LDS size) —
     // a progressive loop issues the same launch hundreds of times
@@ -1734,8 +1849,20 @@ static hipError_t launch_render_tree(const RenderArgs& A, size_t lds, hipStream_
     if (hipGetDevice(&dev) != hipSuccess) dev = -2;
     if (dev != c_dev || lds != c_lds || c_cap == 0) { c_cap = resident_blocks(k_render<true, MODE, COOPG>, lds); c_dev = dev; c_lds = lds; }
     const unsigned cap = c_cap;
-    hipLaunchKernelGGL((k_render<true, MODE, COOPG>), dim3(need < cap ? need : cap), dim3(256), lds, st, A);
+    return need < cap ? need : cap;
+}
+template <int MODE, int COOPG>
+static hipError_t launch_render_tree(const RenderArgs& A, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_render<true, MODE, COOPG>), dim3(tree_grid_blocks<MODE, COOPG>(A, lds)), dim3(256), lds, st, A);
     return hipGetLastError();
+}
+// the same for a tree variant chosen at run time (the scheduling pass wants the grid's lanes before the launch)
+static unsigned render_grid_blocks(const RenderArgs& A, int variant, int mode) {
+    const size_t lds = tree_lds_bytes(A.tree.n_nodes, variant != 1);
+    if (variant == 5) return mode == 0 ? tree_grid_blocks<0, 5>(A, lds) : tree_grid_blocks<1, 5>(A, lds);
+    if (variant == 4) return mode == 0 ? tree_grid_blocks<0, 4>(A, lds) : tree_grid_blocks<1, 4>(A, lds);
+    if (variant == 2) return mode == 0 ? tree_grid_blocks<0, 2>(A, lds) : tree_grid_blocks<1, 2>(A, lds);
+    return mode == 0 ? tree_grid_blocks<0, 1>(A, lds) : tree_grid_blocks<1, 1>(A, lds);
 }
 
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st) {

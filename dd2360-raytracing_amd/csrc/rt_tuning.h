@@ -23,6 +23,27 @@
 #ifndef RT_LONG_CHECK
 #define RT_LONG_CHECK 4         // a pixel's rate is looked at every so many samples (a power of two).  C3: 2: 17.9 ms, 4: 16.93, 8: 17.5
 #endif
+// "Long" relative to the launch (k_tile_order): the pilot's bounce counts predict the launch's iterations; iterations / lanes of the
+// persistent grid = the LOAD one lane works through.  A pixel is long when its predicted chain (rate x ns) reaches RT_F_INFLIGHT x
+// load (found in flight, next to the rate rule above) or RT_F_STATIC x load (3x3 pilot sum, next to RT_PILOT_LONG_SUM: the lower
+// threshold counts).  C3's tuned constants are these in disguise (load 663: 14 bounces/sample x 64 = 1.35 x load, pilot sum 200 =
+// 1.07 x load), so C3 does not move; an eighth of the C5 frame (load 2 250) needs them where the whole frame (18 000) does not.
+// Environment variables of the same names override the values per process (tuning sweeps on one build).  0 = off.
+#ifndef RT_F_INFLIGHT
+#define RT_F_INFLIGHT 1.35f
+#endif
+#ifndef RT_F_STATIC
+#define RT_F_STATIC 1.07f
+#endif
+#ifndef RT_F_TAIL
+#define RT_F_TAIL 0.15f         // share of a launch's predicted work whose pixels are handed out one by one, most expensive 2x2 pilot block first, at the end of the
+#endif                          // queue (k_tail_order) instead of tile by tile; 0 = off
+#ifndef RT_LONG_RATE_MIN
+#define RT_LONG_RATE_MIN 8      // ... but never below this many bounces per sample / this 3x3 pilot sum (launches of a pixel or two per lane)
+#endif
+#ifndef RT_PILOT_LONG_SUM_MIN
+#define RT_PILOT_LONG_SUM_MIN 120
+#endif
 #ifndef RT_MED_RATE
 #define RT_MED_RATE 12          // "medium" chains (below RT_LONG_RATE): the wave keeps refilling but issues at priority 1; 0 = off.  C3 (round 1): off 22.88 ms, 10: 22.62, 12: 22.51, 15: 22.53
 #endif
