@@ -17,8 +17,11 @@
 #include "../host/rt_image.hpp"
 
 namespace rt {
-hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st);
+hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, long long begin, long long end, hipStream_t st);
 hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st);
+hipError_t launch_pilot(const RenderArgs& A, bool tree, int* cost, unsigned char* pilot, int* work, hipStream_t st);
+hipError_t launch_pilot_h(const RenderArgs& A, bool tree, int* cost, hipStream_t st);
+hipError_t launch_assemble_split(void* full, const void* parts, int max_x, int max_y, int nparts, const long long* starts, long long part_stride_px, bool half, hipStream_t st);
 hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st);
 namespace fmac { hipError_t launch_render(const RenderArgs& A, bool tree, int mode, hipStream_t st); }      // rt_kernels_contract.hip
 hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st);
@@ -101,7 +104,13 @@ static rt_octree* ensure_list_tree(const rt_world* W) {
     return Z.list_tree;
 }
 
-static bool valid_partition(rt_partition p) { return p.nparts >= 1 && p.part >= 0 && p.part < p.nparts; }
+static bool valid_partition(rt_partition p) {
+    if (!(p.nparts >= 1 && p.part >= 0 && p.part < p.nparts)) return false;
+    if (p.tile_begin == 0 && p.tile_end == 0) return true;                          // runs of RT_PART_RUN tiles
+    return p.tile_begin >= 0 && p.tile_end > p.tile_begin;                          // a range of tiles (checked against the frame where the frame is known)
+}
+static bool range_in_frame(rt_partition p, int64_t tiles) { return p.tile_end <= p.tile_begin || p.tile_end <= tiles; }
+static int64_t local_tiles_of(int64_t tiles, rt_partition p) { return part_local_tiles(tiles, p.part, p.nparts, p.tile_begin, p.tile_end); }
 static bool hittable(const rt_sphere& s) { return s.material != RT_MAT_NONE; }
 // radius*radius in real_t (sphere.h:21), as a float image
 static float radius_squared(const rt_sphere& s, int precision) {
@@ -241,18 +250,18 @@ static int ctx_prepare(rt_render_ctx& C) {          // device counters and event
 // device, so launches still queued on it finish first.
 static int ctx_reserve(rt_render_ctx& C, int64_t tiles) {
     if (C.sched_tiles >= tiles) return 0;
-    void* old[4] = {C.d_cost, C.d_order, C.d_flags, C.d_long};
-    C.d_cost = nullptr; C.d_order = nullptr; C.d_flags = nullptr; C.d_long = nullptr; C.sched_tiles = 0;
-    int rc = free_all(old, 4);
+    void* old[5] = {C.d_cost, C.d_order, C.d_flags, C.d_long, C.d_work};
+    C.d_cost = nullptr; C.d_order = nullptr; C.d_flags = nullptr; C.d_long = nullptr; C.d_work = nullptr; C.sched_tiles = 0;
+    int rc = free_all(old, 5);
     if (rc) return rc;
-    void* nw[4] = {nullptr, nullptr, nullptr, nullptr};
-    // (flags: 64 + 16 + 16 bytes per tile; long chains: 64 entries per tile, then the tail list: 16 per tile — at most a quarter of the tiles)
-    const size_t bytes[4] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 96, sizeof(unsigned int) * (size_t)tiles * 80};
-    for (int k = 0; k < 4; ++k) {
+    void* nw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // (flags: 64 + 16 + 16 bytes per tile; long chains: 64 entries per tile, then the tail list: up to 64 per tile)
+    const size_t bytes[5] = {sizeof(int) * (size_t)tiles, sizeof(unsigned int) * (size_t)tiles, (size_t)tiles * 96, sizeof(unsigned int) * (size_t)tiles * 128, sizeof(int) * (size_t)tiles * 2};
+    for (int k = 0; k < 5; ++k) {
         const hipError_t e = hipMalloc(&nw[k], bytes[k]);
-        if (e != hipSuccess) { (void)free_all(nw, 4); return (int)e; }
+        if (e != hipSuccess) { (void)free_all(nw, 5); return (int)e; }
     }
-    C.d_cost = (int*)nw[0]; C.d_order = (unsigned int*)nw[1]; C.d_flags = (unsigned char*)nw[2]; C.d_long = (unsigned int*)nw[3];
+    C.d_cost = (int*)nw[0]; C.d_order = (unsigned int*)nw[1]; C.d_flags = (unsigned char*)nw[2]; C.d_long = (unsigned int*)nw[3]; C.d_work = (int*)nw[4];
     C.sched_tiles = tiles;
     return 0;
 }
@@ -274,9 +283,9 @@ static int ctx_reserve_progressive(rt_render_ctx& C, int64_t tiles) {
     return 0;
 }
 static int ctx_release(rt_render_ctx& C) {
-    void* bufs[7] = {C.d_queue, C.d_cost, C.d_order, C.d_flags, C.d_long, C.p_cost, C.p_order};
-    const int rc = free_all(bufs, 7);
-    C.d_queue = nullptr; C.d_cost = nullptr; C.d_order = nullptr; C.d_flags = nullptr; C.d_long = nullptr; C.sched_tiles = 0;
+    void* bufs[8] = {C.d_queue, C.d_cost, C.d_order, C.d_flags, C.d_long, C.p_cost, C.p_order, C.d_work};
+    const int rc = free_all(bufs, 8);
+    C.d_queue = nullptr; C.d_cost = nullptr; C.d_order = nullptr; C.d_flags = nullptr; C.d_long = nullptr; C.d_work = nullptr; C.sched_tiles = 0;
     C.p_cost = nullptr; C.p_order = nullptr; C.p_tiles = 0; C.p_valid = false;
     for (int k = 0; k < 64; ++k) { if (C.ev0[k]) (void)hipEventDestroy(C.ev0[k]); if (C.ev1[k]) (void)hipEventDestroy(C.ev1[k]); C.ev0[k] = nullptr; C.ev1[k] = nullptr; }
     if (C.done) (void)hipEventDestroy(C.done);
@@ -298,7 +307,8 @@ int rt_render_ctx_reserve(rt_render_ctx* C, int max_x, int max_y, rt_partition p
     if (!C || max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
     const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
     const int rc = ctx_prepare(*C);
-    return rc ? rc : ctx_reserve(*C, part_local_tiles(tiles, part.part, part.nparts));
+    if (!range_in_frame(part, tiles)) return RT_EINVAL;
+    return rc ? rc : ctx_reserve(*C, local_tiles_of(tiles, part));
 }
 int rt_render_ctx_destroy(rt_render_ctx* C) {
     if (!C) return 0;
@@ -658,16 +668,19 @@ int rt_build_octree_gpu(const rt_world* world, int spheres_per_leaf, rt_octree**
 // ------------------------------------------------------------------------------------------------ the hot path
 int64_t rt_part_pixels(int max_x, int max_y, rt_partition part) {
     if (max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
-    if (part.nparts == 1) return (int64_t)max_x * max_y;
+    if (part_whole(part.nparts, part.tile_begin, part.tile_end)) return (int64_t)max_x * max_y;
     const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
-    return part_local_tiles(tiles, part.part, part.nparts) * 64;
+    if (!range_in_frame(part, tiles)) return RT_EINVAL;
+    return local_tiles_of(tiles, part) * 64;
 }
 
 int rt_render_init(int max_x, int max_y, rt_rand_state* d_rand_state, rt_partition part, void* stream) {
     if (max_x <= 0 || max_y <= 0 || !valid_partition(part)) return RT_EINVAL;
-    if (rt_part_pixels(max_x, max_y, part) == 0) return 0;            // a part without tiles (more parts than tiles): nothing to do
+    const int64_t npx = rt_part_pixels(max_x, max_y, part);
+    if (npx < 0) return RT_EINVAL;
+    if (npx == 0) return 0;                                              // a part without tiles (more parts than tiles): nothing to do
     if (!d_rand_state) return RT_EINVAL;
-    return (int)launch_render_init(d_rand_state, max_x, max_y, part.part, part.nparts, (hipStream_t)stream);
+    return (int)launch_render_init(d_rand_state, max_x, max_y, part.part, part.nparts, part.tile_begin, part.tile_end, (hipStream_t)stream);
 }
 
 // no octree passed: the world's one-node list tree, if it has one and the fast list traversal is selected
@@ -709,7 +722,7 @@ static bool capturing(hipStream_t st) {
 static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int ns, const rt_world* world, rt_rand_state* d_rand_state, const rt_octree* d_octree, rt_partition part, void* stream, int mode) {
     if (!world || max_x <= 0 || max_y <= 0 || ns <= 0 || !valid_partition(part)) return RT_EINVAL;
     if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
-    if (rt_part_pixels(max_x, max_y, part) == 0) return 0;            // a part without tiles (more parts than tiles): nothing to do
+    { const int64_t npx = rt_part_pixels(max_x, max_y, part); if (npx < 0) return RT_EINVAL; if (npx == 0) return 0; }   // (a part without tiles — more parts than tiles: nothing to do)
     if (!fb || !d_rand_state) return RT_EINVAL;
     const hipStream_t st = (hipStream_t)stream;
     const bool cap = capturing(st);
@@ -721,9 +734,9 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     RenderArgs A;
     A.fb = fb; A.rand_state = d_rand_state; A.max_x = max_x; A.max_y = max_y; A.ns = ns;
     A.tiles_x = (max_x + 7) / 8; A.tiles_y = (max_y + 7) / 8;
-    A.part = part.part; A.nparts = part.nparts;
+    A.part = part.part; A.nparts = part.nparts; A.tile_begin = part.tile_begin; A.tile_end = part.tile_end;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
-    A.n_local_tiles = part_local_tiles(tiles, part.part, part.nparts);
+    A.n_local_tiles = local_tiles_of(tiles, part);
     A.scene = world->z->dev;
     A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
@@ -749,7 +762,8 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
         // 0.5 ms).  The long-chain list is not kept: a pass is one sample, and waves set aside for the crevice pixels' ~40 bounces cost
         // a pass more than they save (0.70 - 0.88 ms).  Scheduling only: which lane renders a pixel and when never changes the pixel.
         const uint64_t key[5] = {world->serial, d_octree ? d_octree->serial : 0, ((uint64_t)(uint32_t)max_x << 32) | (uint32_t)max_y,
-                                 ((uint64_t)(uint32_t)part.part << 32) | (uint32_t)part.nparts, (uint64_t)(d_octree ? d_octree->traversal : 0)};
+                                 (((uint64_t)(uint32_t)part.part << 32) | (uint32_t)part.nparts) ^ ((uint64_t)part.tile_begin * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)part.tile_end << 20),
+                                 (uint64_t)(d_octree ? d_octree->traversal : 0)};
         if (ns == 1 && !cap) {
             C.p_valid = false;
             if ((rc = ctx_reserve_progressive(C, A.n_local_tiles))) return rc;
@@ -861,6 +875,71 @@ int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int n
     if (precision == RT_PRECISION_FP16) return (int)launch_assemble_h(fb_full, fb_parts, max_x, max_y, nparts, (hipStream_t)stream);
     if (precision != RT_PRECISION_FP32) return RT_EINVAL;
     return (int)launch_assemble((float*)fb_full, (const float*)fb_parts, max_x, max_y, nparts, (hipStream_t)stream);
+}
+
+int rt_assemble_split(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, const int64_t* starts, int64_t part_stride_px, int precision, void* stream) {
+    if (!fb_full || !fb_parts || !starts || max_x <= 0 || max_y <= 0 || nparts < 1 || nparts > rt::kMaxSplitParts || part_stride_px < 0) return RT_EINVAL;
+    if (precision != RT_PRECISION_FP32 && precision != RT_PRECISION_FP16) return RT_EINVAL;
+    const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
+    if (starts[0] != 0 || starts[nparts] != tiles) return RT_EINVAL;
+    long long st64[rt::kMaxSplitParts + 1];
+    for (int p = 0; p <= nparts; ++p) { if (p && starts[p] < starts[p - 1]) return RT_EINVAL; if (p && (starts[p] - starts[p - 1]) * 64 > part_stride_px && nparts > 1) return RT_EINVAL; st64[p] = starts[p]; }
+    return (int)launch_assemble_split(fb_full, fb_parts, max_x, max_y, nparts, st64, part_stride_px, precision == RT_PRECISION_FP16, (hipStream_t)stream);
+}
+
+// rt_split_balanced: the pilot pass over the whole frame, the counts to the host, the cuts in integer arithmetic
+int rt_split_balanced(rt_render_ctx* ctx, const rt_world* world, const rt_octree* d_octree, int max_x, int max_y, int nparts, int64_t* starts,
+                      int32_t* tile_bounces, int32_t* tile_tests, int32_t* tile_columns, void* stream) {
+    if (!world || !starts || max_x <= 0 || max_y <= 0 || nparts < 1 || nparts > rt::kMaxSplitParts) return RT_EINVAL;
+    if (d_octree && d_octree->precision != world->precision) return RT_EINVAL;
+    const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
+    if (tiles < nparts) return RT_EINVAL;
+    const hipStream_t st = (hipStream_t)stream;
+    if (capturing(st)) return RT_EINVAL;
+    int rc = ensure_on_device(world, d_octree);
+    rt_render_ctx& C = ctx ? *ctx : world->z->ctx;
+    if (!rc) rc = ctx_prepare(C);
+    if (!rc) rc = ctx_reserve(C, tiles);
+    if (rc) return rc;
+    if (C.has_done && C.last_stream != st) RT_TRY(hipStreamWaitEvent(st, C.done, 0));      // (the workspace is shared with the context's renders)
+    RenderArgs A;
+    memset(&A, 0, sizeof(A));
+    A.max_x = max_x; A.max_y = max_y; A.ns = 1;
+    A.tiles_x = (max_x + 7) / 8; A.tiles_y = (max_y + 7) / 8;
+    A.part = 0; A.nparts = 1; A.tile_begin = 0; A.tile_end = 0;
+    A.n_local_tiles = tiles;
+    A.scene = world->z->dev;
+    A.tree = tree_args(d_octree);
+    const bool half = world->precision == RT_PRECISION_FP16;
+    RT_TRY(hipMemsetAsync(C.d_work, 0, sizeof(int) * (size_t)tiles * 2, st));
+    if (half) RT_TRY(launch_pilot_h(A, d_octree != nullptr, C.d_cost, st));
+    else RT_TRY(launch_pilot(A, d_octree != nullptr, C.d_cost, nullptr, C.d_work, st));
+    std::vector<int32_t> cost, work;
+    try { cost.resize((size_t)tiles); work.resize((size_t)tiles * 2); } catch (const std::bad_alloc&) { return RT_ENOMEM; }
+    RT_TRY(hipMemcpyAsync(cost.data(), C.d_cost, sizeof(int) * (size_t)tiles, hipMemcpyDeviceToHost, st));
+    RT_TRY(hipMemcpyAsync(work.data(), C.d_work, sizeof(int) * (size_t)tiles * 2, hipMemcpyDeviceToHost, st));
+    RT_TRY(hipEventRecord(C.done, st)); C.has_done = true; C.last_stream = st;
+    RT_TRY(hipStreamSynchronize(st));
+    // a tile's cost: wb x bounces + wt x tests + wc x columns (rt_tuning.h RT_SPLIT_W*: integer weights fitted to measured band times)
+    const int64_t wb = (int64_t)tune_value("RT_SPLIT_WB", RT_SPLIT_WB), wt = (int64_t)tune_value("RT_SPLIT_WT", RT_SPLIT_WT), wc = (int64_t)tune_value("RT_SPLIT_WC", RT_SPLIT_WC);
+    const int32_t* cols = work.data() + tiles;
+    int64_t total = 0;
+    for (int64_t t = 0; t < tiles; ++t) {
+        cost[t] /= 4;                                                     // (k_tile_cost stores 4 x the bounces of the tile's pilot samples)
+        if (tile_bounces) tile_bounces[t] = cost[t];
+        if (tile_tests) tile_tests[t] = work[t];
+        if (tile_columns) tile_columns[t] = cols[t];
+        total += wb * cost[t] + wt * work[t] + wc * cols[t];
+    }
+    starts[0] = 0; starts[nparts] = tiles;
+    int64_t run = 0, t = 0;
+    for (int p = 1; p < nparts; ++p) {
+        // the first tile at which the running cost has passed p/nparts of the total — but every band keeps at least one tile
+        const int64_t want = (total / nparts) * p + (total % nparts) * p / nparts;
+        while (t < tiles - (nparts - p) && (run < want || t < starts[p - 1] + 1)) { run += wb * cost[t] + wt * work[t] + wc * cols[t]; ++t; }
+        starts[p] = t;
+    }
+    return 0;
 }
 
 int rt_trace_rays(const rt_world* world, const rt_octree* d_octree, const float* d_rays, int64_t n, rt_hit_record* d_out, void* stream) {

@@ -15,27 +15,39 @@ constexpr float kRootHalfXZf = (float)kRootHalfXZ, kInvCellXZf = 1.0f / 2.75f, k
 static_assert(kCellXZ == 2.75 && 1.0 / kCellY == 4.0, "level-3 cells of the reference's root box");
 
 
-// The tile split of a frame over parts (rt_amd.h, rt_partition): runs of RT_PART_RUN consecutive tiles dealt round-robin.
-// Every kernel and the host go through these three functions — nothing else knows the mapping.
+// The tile split of a frame over parts (rt_amd.h, rt_partition).  Two forms: a contiguous range [begin, end) of the row-major tile
+// numbering (end > begin: rt_split_balanced cuts the frame into such bands of equal predicted cost), or — begin == end == 0 — runs of
+// RT_PART_RUN consecutive tiles dealt round-robin.  Every kernel and the host go through these functions: nothing else knows the mapping.
 #ifndef RT_PART_RUN_BUILD
 #define RT_PART_RUN_BUILD RT_PART_RUN           // (tools/mkvariant.sh -DRT_PART_RUN_BUILD=n: A/B of the run length)
 #endif
 constexpr long long kPartRun = RT_PART_RUN_BUILD;
-__host__ __device__ inline long long part_tile(long long local_tile, int part, int nparts) {          // global tile of a part's local tile
+__host__ __device__ inline bool part_whole(int nparts, long long begin, long long end) { return nparts == 1 && end <= begin; }   // the undivided frame: row-major buffers
+__host__ __device__ inline long long part_tile(long long local_tile, int part, int nparts, long long begin = 0, long long end = 0) {          // global tile of a part's local tile
+    if (end > begin) return begin + local_tile;
     if (nparts == 1) return local_tile;
     return ((local_tile / kPartRun) * nparts + part) * kPartRun + local_tile % kPartRun;
 }
-__host__ __device__ inline long long part_local_tiles(long long tiles, int part, int nparts) {        // tiles of the frame that belong to `part`
+__host__ __device__ inline long long part_local_tiles(long long tiles, int part, int nparts, long long begin = 0, long long end = 0) {        // tiles of the frame that belong to `part`
+    if (end > begin) return end - begin;
     const long long round = (long long)nparts * kPartRun;
     long long extra = tiles % round - (long long)part * kPartRun;
     extra = extra < 0 ? 0 : (extra > kPartRun ? kPartRun : extra);
     return tiles / round * kPartRun + extra;
 }
-__host__ __device__ inline void part_owner(long long tile, int nparts, int& part, long long& local_tile) {   // inverse of part_tile
+__host__ __device__ inline void part_owner(long long tile, int nparts, int& part, long long& local_tile) {   // inverse of part_tile (runs)
     const long long run = tile / kPartRun;
     part = (int)(run % nparts);
     local_tile = (run / nparts) * kPartRun + tile % kPartRun;
 }
+// is `tile` one of this part's, and which of its local tiles
+__host__ __device__ inline bool part_has(long long tile, int part, int nparts, long long begin, long long end, long long& local_tile) {
+    if (end > begin) { local_tile = tile - begin; return tile >= begin && tile < end; }
+    int owner; part_owner(tile, nparts, owner, local_tile);
+    return owner == part;
+}
+constexpr int kMaxSplitParts = 64;
+struct SplitStarts { long long s[kMaxSplitParts + 1]; };      // first tile of every band of a balanced split, and the tile count (k_assemble_split)
 
 // One node of the traversal copy of the Octree, in depth-first pre-order (children in index order, the visit
 // order of traverseTree, acceleration_structure.h:276-304).  48 bytes = 3 x 16 B so a lane fetches it with
@@ -118,6 +130,7 @@ struct RenderArgs {
     int32_t max_x, max_y, ns;             // ns = current_sample for the progressive kernel
     int32_t tiles_x, tiles_y;
     int32_t part, nparts;
+    int64_t tile_begin, tile_end;         // end > begin: this part is the contiguous tile range [begin, end) (local tile = tile - begin)
     int64_t n_local_tiles;
     unsigned int* queue;                  // counters of this launch, zeroed on the stream: [0] work counter [1] thin waves [2] long chains [3] long head
                                           // [4] solo chains [5] solo head; in the slot's second 128-byte line, written by k_tile_order before the render kernel starts and

@@ -22,7 +22,7 @@ struct rt_render_ctx {
     // work counters of the persistent render kernel: a ring of slots (one per launch, 256 B apart), zeroed on the stream
     unsigned int* d_queue = nullptr; unsigned launches = 0;
     // scheduling workspace (tile costs, hand-out order, long-chain flags and list), grown on demand
-    int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int64_t sched_tiles = 0;
+    int* d_cost = nullptr; unsigned int* d_order = nullptr; unsigned char* d_flags = nullptr; unsigned int* d_long = nullptr; int* d_work = nullptr; int64_t sched_tiles = 0;
     unsigned int* last_queue = nullptr;      // the counters of the latest launch (rt_render_ctx_counters)
     // tile order of a progressive sequence (rt_render_progressive): the pilot pass that the call with current_sample == 1 runs, kept
     // in buffers of its own and reused by the following passes of the same frame (p_key: world and tree serials, frame size, partition)

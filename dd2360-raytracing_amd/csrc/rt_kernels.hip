@@ -381,6 +381,8 @@ struct Walk {                // a ray's walk over the grid, in cell units along 
     int i, iend, coff;      // next column, end (exclusive, in travel direction), offset of the x- or z-major grid copy
     float om_c, on_c, slope, dm_c;
     bool fwd, walking;
+    unsigned work, cols;    // grid entries this ray's columns have put into the wave's pool, and the columns it stepped through (read by the pilot pass only:
+                            // a tile's cost in time — a ray along the horizon crosses hundreds of columns, most of them empty)
 };
 
 // last column worth visiting once a hit at best_t is known: its entry edge is within back_c of the hit point
@@ -394,6 +396,7 @@ RT_DEV void walk_clip(Walk& W, const DevAccel& A, float best_t) {
 
 RT_DEV Walk walk_setup(const DevAccel& A, const RayF& r, float best_t, int best) {
     Walk W;
+    W.work = 0u; W.cols = 0u;
     const int G = A.G;
     const float fG = (float)G;
     const float slack = 2e-3f;
@@ -565,7 +568,7 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
                     const unsigned cbase = (unsigned)(W.coff + W.i * G);
                     e0[c] = cs[cbase + (unsigned)k0]; e1[c] = cs[cbase + (unsigned)k1 + 1u];
                 }
-                W.i += step;
+                W.i += step; ++W.cols;
             }
         }
         unsigned n_seg = 0u;                                         // (<= 64 x RT_POOL_COLS: the pool cannot overflow)
@@ -577,6 +580,7 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
             if (has) {
                 const unsigned slot = n_seg + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 L.seg[slot] = make_uint2((unsigned)e0[c], (unsigned)(e1[c] - e0[c]) | ((unsigned)lane << 26));
+                W.work += (unsigned)(e1[c] - e0[c]);
             }
             n_seg += (unsigned)__popcll(m);
         }
@@ -739,7 +743,7 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
                 const unsigned cbase = (unsigned)(W.coff + W.i * G);
                 e0 = cs[cbase + (unsigned)k0]; e1 = cs[cbase + (unsigned)k1 + 1u];
             }
-            W.i += step;
+            W.i += step; ++W.cols;
         }
         const bool has = e1 > e0;
         const unsigned long long m = __ballot(has);
@@ -747,6 +751,7 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
         if (has) {
             const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             L.seg[slot] = make_uint2((unsigned)e0, (unsigned)(e1 - e0) | ((unsigned)lane << 26));
+            W.work += (unsigned)(e1 - e0);
         }
         walk_sync();
         if (n_seg != 0u) {
@@ -877,9 +882,9 @@ RT_DEV void stage_tree_fp32(const DevScene& S, const DevTree& T, float4* s_nodes
     __syncthreads();
 }
 
-struct TreeState { Walk W; float g_t; int g_id; bool tie, pending; };
+struct TreeState { Walk W; float g_t; int g_id; bool tie, pending; unsigned work, cols; };
 RT_DEV void tree_state_init(TreeState& ts) {
-    ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1;
+    ts.pending = false; ts.tie = false; ts.g_t = FLT_MAX; ts.g_id = -1; ts.work = 0u; ts.cols = 0u; ts.W.work = 0u; ts.W.cols = 0u;
     ts.W.walking = false; ts.W.i = 0; ts.W.iend = 0; ts.W.coff = 0; ts.W.om_c = 0.f; ts.W.on_c = 0.f; ts.W.slope = 0.f; ts.W.dm_c = 0.f; ts.W.fwd = true;
 }
 
@@ -956,7 +961,7 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
             // per column — that walk filters against a stale best hit: 1281 ms against 670 for walk_pool_dense, which re-reads it)
             if (COOPG >= 4) walk_pool<RT_QUORUM_SPARSE>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
             else walk_pool_dense<RT_QUORUM_DENSE>(T, s_nodes, L, r, a, Wl, bt, bi, tt STAT_PASS);
-            if (walker) { ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
+            if (walker) { ts.work += Wl.work; ts.cols += Wl.cols; Wl.work = 0u; Wl.cols = 0u; ts.W = Wl; closest = bt; best = bi; ts.tie = ts.tie || tt; }
         }
         if (walker) {
             ts.pending = ts.W.walking;
@@ -1089,16 +1094,17 @@ RT_DEV V3 sky(const RayF& r, const V3& att) {
 
 // ---------------------------------------------------------------------------------------------------- kernels
 #ifndef RT_TU_LIST
-__global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, int max_x, int max_y, int tiles_x, int part, int nparts, long long n_local_tiles) {
+__global__ __launch_bounds__(256) void k_render_init(rt_rand_state* rand_state, int max_x, int max_y, int tiles_x, int part, int nparts, long long begin, long long end, long long n_local_tiles) {
     const int lane = threadIdx.x & 63;
     const long long local_tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (local_tile >= n_local_tiles) return;
-    const long long tile = part_tile(local_tile, part, nparts);
+    const long long tile = part_tile(local_tile, part, nparts, begin, end);
     const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
     const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
     const bool inside = (i < max_x) && (j < max_y);
-    if (nparts == 1 && !inside) return;
-    const long long idx = (nparts == 1) ? (long long)j * max_x + i : local_tile * 64 + lane;
+    const bool whole = part_whole(nparts, begin, end);
+    if (whole && !inside) return;
+    const long long idx = whole ? (long long)j * max_x + i : local_tile * 64 + lane;
     const int pixel_index = j * max_x + i;
     Rng s; rng_seed(s, 1984ull + (unsigned long long)(long long)pixel_index);
     rt_rand_state out;
@@ -1200,12 +1206,12 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                 l = (int)(within / tiles_in_blk);
                 local_tile = A.order ? (long long)A.order[rank] : rank;
             }
-            const long long tile = part_tile(local_tile, A.part, A.nparts);
+            const long long tile = part_tile(local_tile, A.part, A.nparts, A.tile_begin, A.tile_end);
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
             const bool taken = use_long && A.long_flag[local_tile * 64 + l];      // long chains are handed out separately
             if (i < A.max_x && j < A.max_y && !taken) {
-                idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l;
+                idx = part_whole(A.nparts, A.tile_begin, A.tile_end) ? (long long)j * A.max_x + i : local_tile * 64 + l;
                 live = true;
                 RT_STATS_ONLY(
                 pix_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1243,10 +1249,10 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         }
         const long long local_tile = pid >> 6;
         const int l = (int)(pid & 63);
-        const long long tile = part_tile(local_tile, A.part, A.nparts);
+        const long long tile = part_tile(local_tile, A.part, A.nparts, A.tile_begin, A.tile_end);
         const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
         i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
-        idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
+        idx = part_whole(A.nparts, A.tile_begin, A.tile_end) ? (long long)j * A.max_x + i : pid;
         live = true; iters = 0; is_long = true;
         RT_STATS_ONLY(
         pix_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1444,7 +1450,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
 // neighbourhood reaches RT_PILOT_LONG_SUM bounces (k_long_select) are listed as long chains, which the render kernel starts first, in thin waves.
 // All of this changes only WHICH lane renders a pixel and WHEN, never the pixel.
 template <bool TREE, int COOPG = 1>
-__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ pilot) {
+__global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict__ cost, unsigned char* __restrict__ pilot, int* __restrict__ work) {
     extern __shared__ float4 s_nodes[];
     if (TREE) stage_tree_fp32<COOPG != 1>(A.scene, A.tree, s_nodes);
     const int lane = threadIdx.x & 63;
@@ -1454,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     static_assert(RT_PILOT_SAMPLES == 1 || RT_PILOT_SAMPLES == 2 || RT_PILOT_SAMPLES == 4, "pilot samples per pixel");
     const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kTilesPerWave + lane / kPerTile;
     const bool tile_ok = local_tile < A.n_local_tiles;
-    const long long tile = part_tile(tile_ok ? local_tile : 0, A.part, A.nparts);
+    const long long tile = part_tile(tile_ok ? local_tile : 0, A.part, A.nparts, A.tile_begin, A.tile_end);
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int sub = (lane % kPerTile) / RT_PILOT_SAMPLES, smp = lane % RT_PILOT_SAMPLES;
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
@@ -1475,11 +1481,13 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     )
     float closest = FLT_MAX; int best = -1;
     TreeState ts; tree_state_init(ts);
+    int lane_iters = 0;          // passes of this loop the path was alive for: its bounces plus the passes a long walk stayed pending (quorum) — the lane-time it costs
     while (__ballot(live) != 0ull) {
         const float a = dot3(r.d, r.d);
         if (!TREE) { closest = FLT_MAX; best = -1; }
         if (TREE) closest_tree<COOPG>(A.scene, A.tree, s_nodes, r, a, live, closest, best, ts STAT_PASS);
         else closest_list(A.scene, r, a, live, closest, best);
+        if (live) ++lane_iters;
         if (live && !(TREE && ts.pending)) {
             ++bounces;
             bool done = true;
@@ -1496,6 +1504,14 @@ __global__ __launch_bounds__(256) void k_tile_cost(RenderArgs A, int* __restrict
     int w = inside ? bounces : 0;
     for (int off = kPerTile / 2; off > 0; off >>= 1) w += __shfl_xor(w, off);         // sum over the tile's 16 pilot pixels x samples
     if (lane % kPerTile == 0 && tile_ok) cost[local_tile] = w * 4;
+    if (work) {                                                                       // (rt_split_balanced: what the tile's walks tested)
+        int tw = inside ? (int)ts.work : 0;
+        for (int off = kPerTile / 2; off > 0; off >>= 1) tw += __shfl_xor(tw, off);
+        int tc = inside ? lane_iters : 0;
+        for (int off = kPerTile / 2; off > 0; off >>= 1) tc += __shfl_xor(tc, off);
+        if (lane % kPerTile == 0 && tile_ok) { work[local_tile] = tw; work[A.n_local_tiles + local_tile] = tc; }       // [tiles] tests, [tiles] lane passes
+        (void)ts.cols;
+    }
 }
 
 RT_DEV int cost_class(int w) { const int c = (w - 64) / 64; return c < 0 ? 0 : (c > 7 ? 7 : c); }
@@ -1509,7 +1525,7 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
     if (g >= A.n_local_tiles * 16) return;
     const long long local_tile = g >> 4;
     const int sub = (int)(g & 15);
-    const long long tile = part_tile(local_tile, A.part, A.nparts);
+    const long long tile = part_tile(local_tile, A.part, A.nparts, A.tile_begin, A.tile_end);
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int bx = tx * 4 + (sub & 3), by = ty * 4 + (sub >> 2);
     const int own = pilot[g];
@@ -1521,9 +1537,8 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
             const int nx_ = bx + dx, ny_ = by + dy;
             int v = own;
             if (nx_ >= 0 && ny_ >= 0 && nx_ < A.tiles_x * 4 && ny_ < A.tiles_y * 4) {
-                int owner; long long nl;
-                part_owner((long long)(ny_ >> 2) * A.tiles_x + (nx_ >> 2), A.nparts, owner, nl);
-                if (owner == A.part) v = pilot[nl * 16 + (ny_ & 3) * 4 + (nx_ & 3)];
+                long long nl;
+                if (part_has((long long)(ny_ >> 2) * A.tiles_x + (nx_ >> 2), A.part, A.nparts, A.tile_begin, A.tile_end, nl)) v = pilot[nl * 16 + (ny_ & 3) * 4 + (nx_ & 3)];
             }
             sum += v;
         }
@@ -1713,6 +1728,34 @@ __global__ __launch_bounds__(256) void k_assemble(float* full, const float* part
 }
 #endif
 
+// the same for the bands of a balanced split (rt_split_balanced): band p holds the tiles [starts.s[p], starts.s[p + 1]), its buffer begins
+// part_stride_px elements behind band p - 1's.  One kernel for both precisions (T = float / uint16_t).
+#ifndef RT_TU_LIST
+template <class T>
+__global__ __launch_bounds__(256) void k_assemble_split(T* full, const T* parts, int max_x, int max_y, int tiles_x, int nparts, long long part_stride_px, SplitStarts starts) {
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= starts.s[nparts]) return;
+    const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+    if (i >= max_x || j >= max_y) return;
+    int owner = 0;
+    for (int p = 1; p < nparts; ++p) owner += tile >= starts.s[p] ? 1 : 0;
+    const long long src = owner * part_stride_px + (tile - starts.s[owner]) * 64 + lane;
+    const long long dst = (long long)j * max_x + i;
+    full[dst * 3 + 0] = parts[src * 3 + 0]; full[dst * 3 + 1] = parts[src * 3 + 1]; full[dst * 3 + 2] = parts[src * 3 + 2];
+}
+hipError_t launch_assemble_split(void* full, const void* parts, int max_x, int max_y, int nparts, const long long* starts, long long part_stride_px, bool half, hipStream_t st) {
+    SplitStarts S;
+    for (int p = 0; p <= nparts; ++p) S.s[p] = starts[p];
+    const int tiles_x = (max_x + 7) / 8;
+    const unsigned blocks = (unsigned)((starts[nparts] + 3) / 4);
+    if (half) hipLaunchKernelGGL((k_assemble_split<uint16_t>), dim3(blocks), dim3(256), 0, st, (uint16_t*)full, (const uint16_t*)parts, max_x, max_y, tiles_x, nparts, part_stride_px, S);
+    else hipLaunchKernelGGL((k_assemble_split<float>), dim3(blocks), dim3(256), 0, st, (float*)full, (const float*)parts, max_x, max_y, tiles_x, nparts, part_stride_px, S);
+    return hipGetLastError();
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------- launchers
 #ifndef RT_TU_LIST
 // Zeroes the work counters of a launch.  A kernel of our own instead of hipMemsetAsync: captured into a hipGraph, the memset
@@ -1723,13 +1766,13 @@ hipError_t launch_zero_counters(unsigned int* p, int n, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, hipStream_t st) {
+hipError_t launch_render_init(rt_rand_state* rs, int max_x, int max_y, int part, int nparts, long long begin, long long end, hipStream_t st) {
     const int tiles_x = (max_x + 7) / 8, tiles_y = (max_y + 7) / 8;
     const long long tiles = (long long)tiles_x * tiles_y;
-    const long long local = part_local_tiles(tiles, part, nparts);
+    const long long local = part_local_tiles(tiles, part, nparts, begin, end);
     if (local <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((local + 3) / 4);
-    hipLaunchKernelGGL(k_render_init, dim3(blocks), dim3(256), 0, st, rs, max_x, max_y, tiles_x, part, nparts, local);
+    hipLaunchKernelGGL(k_render_init, dim3(blocks), dim3(256), 0, st, rs, max_x, max_y, tiles_x, part, nparts, begin, end, local);
     return hipGetLastError();
 }
 #endif
@@ -1757,7 +1800,7 @@ template <class K> static unsigned resident_blocks(K kernel, size_t lds) {
 #define RT_LIST_FN(name) static name##_list
 #endif
 hipError_t RT_LIST_FN(launch_tile_cost)(const RenderArgs& A, unsigned blocks, int* cost, unsigned char* pilot, hipStream_t st) {
-    hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), 0, st, A, cost, pilot);
+    hipLaunchKernelGGL((k_tile_cost<false>), dim3(blocks), dim3(256), 0, st, A, cost, pilot, (int*)nullptr);
     return hipGetLastError();
 }
 hipError_t RT_LIST_FN(launch_render)(const RenderArgs& A, int mode, hipStream_t st) {
@@ -1807,7 +1850,7 @@ hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int*
     // flags: 64 bytes per local tile (one per pixel), 16 (the pilot's count per 2x2 block), 16 (that count summed over the block's 3x3 neighbourhood)
     const bool tail = flags && A.tail_list && A.f_tail > 0.f;
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles, A.queue, (int)A.ns, (int)A.n_lanes, A.f_inflight, A.f_static,
-                       tail ? A.f_tail : 0.f, (long long)(A.n_local_tiles / 4));
+                       tail ? A.f_tail : 0.f, (long long)A.n_local_tiles);
     if (flags) {
         const unsigned char* pilot = flags + (size_t)A.n_local_tiles * 64;
         unsigned char* sum8 = flags + (size_t)A.n_local_tiles * 80;
@@ -1818,22 +1861,29 @@ hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int*
 }
 
 static unsigned render_grid_blocks(const RenderArgs& A, int variant, int mode);
-hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
+// the pilot pass alone: per tile the bounces (x 4) and — trees with a candidate grid — the grid entries its samples' walks pooled
+hipError_t launch_pilot(const RenderArgs& A, bool tree, int* cost, unsigned char* pilot, int* work, hipStream_t st) {
     if (A.n_local_tiles <= 0) return hipSuccess;
     const long long per_block = 4 * (64 / (16 * RT_PILOT_SAMPLES));       // a wave covers 4 / RT_PILOT_SAMPLES tiles
     const unsigned blocks = (unsigned)((A.n_local_tiles + per_block - 1) / per_block);
-    // (sparse grids: the pilot paths walk the grid like the render kernel's full waves do, through the wave's pool)
-    // flags: 64 bytes per local tile (one per pixel) followed by 16 per local tile (the pilot counts per 2x2 block)
-    unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
     // (the pilot paths walk the grid like the render kernel's waves do, through the wave's pool)
+    const int variant = render_variant(tree, 0, A.tree.acc);
+    if (variant == 5) hipLaunchKernelGGL((k_tile_cost<true, 5>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot, work);
+    else if (variant == 4) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot, work);
+    else if (variant == 2) hipLaunchKernelGGL((k_tile_cost<true, 2>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot, work);
+    else if (tree) hipLaunchKernelGGL((k_tile_cost<true, 1>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot, work);
+    else return launch_tile_cost_list(A, blocks, cost, pilot, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {
+    if (A.n_local_tiles <= 0) return hipSuccess;
+    // flags: 64 bytes per local tile (one per pixel) followed by 16 per local tile (the pilot counts per 2x2 block) and 16 more (k_long_select)
+    unsigned char* pilot = flags ? flags + (size_t)A.n_local_tiles * 64 : nullptr;
     const int variant = render_variant(tree, 0, A.tree.acc);
     RenderArgs B = A;
     B.n_lanes = tree ? (int)render_grid_blocks(A, variant, 0) * 256 : 0;      // (list scans keep the rate rule alone)
-    if (variant == 5) hipLaunchKernelGGL((k_tile_cost<true, 5>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
-    else if (variant == 4) hipLaunchKernelGGL((k_tile_cost<true, 4>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
-    else if (variant == 2) hipLaunchKernelGGL((k_tile_cost<true, 2>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes, true), st, A, cost, pilot);
-    else if (tree) hipLaunchKernelGGL((k_tile_cost<true, 1>), dim3(blocks), dim3(256), tree_lds_bytes(A.tree.n_nodes), st, A, cost, pilot);
-    else { const hipError_t e = launch_tile_cost_list(A, blocks, cost, pilot, st); if (e != hipSuccess) return e; }
+    { const hipError_t e = launch_pilot(A, tree, cost, pilot, nullptr, st); if (e != hipSuccess) return e; }
     // (chains in waves of their own: the variant for very sparse grids)
     return launch_select_and_order(B, cost, order, flags, long_list, st, 0, variant == 5 ? RT_PILOT_SOLO_SUM : 0x7fffffff);
 }

@@ -799,11 +799,11 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
             const long long rank = blk * 64 + within % tiles_in_blk;
             const int l = (int)(within / tiles_in_blk);
             const long long local_tile = A.order ? (long long)A.order[rank] : rank;
-            const long long tile = part_tile(local_tile, A.part, A.nparts);
+            const long long tile = part_tile(local_tile, A.part, A.nparts, A.tile_begin, A.tile_end);
             const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
             i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
             const bool taken = use_long && A.long_flag[local_tile * 64 + l];      // long chains are handed out separately
-            if (i < A.max_x && j < A.max_y && !taken) { idx = (A.nparts == 1) ? (long long)j * A.max_x + i : local_tile * 64 + l; live = true; break; }
+            if (i < A.max_x && j < A.max_y && !taken) { idx = part_whole(A.nparts, A.tile_begin, A.tile_end) ? (long long)j * A.max_x + i : local_tile * 64 + l; live = true; break; }
             slot = first_free + (long long)atomicAdd(A.queue, 1u);
         }
         if (!live) retired = true;
@@ -818,10 +818,10 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
         const long long pid = (long long)A.long_list[(unsigned int)(((unsigned long long)h * stride) % n_long)];
         const long long local_tile = pid >> 6;
         const int l = (int)(pid & 63);
-        const long long tile = part_tile(local_tile, A.part, A.nparts);
+        const long long tile = part_tile(local_tile, A.part, A.nparts, A.tile_begin, A.tile_end);
         const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
         i = tx * 8 + (l & 7); j = ty * 8 + (l >> 3);
-        idx = (A.nparts == 1) ? (long long)j * A.max_x + i : pid;
+        idx = part_whole(A.nparts, A.tile_begin, A.tile_end) ? (long long)j * A.max_x + i : pid;
         live = true; is_long = true;
         start_pixel();
         return true;
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_tile_cost_h(RenderArgs
     // a wave covers two tiles: 16 blocks x 2 samples each
     const long long local_tile = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + lane / 32;
     const bool tile_ok = local_tile < A.n_local_tiles;
-    const long long tile = part_tile(tile_ok ? local_tile : 0, A.part, A.nparts);
+    const long long tile = part_tile(tile_ok ? local_tile : 0, A.part, A.nparts, A.tile_begin, A.tile_end);
     const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
     const int sub = (lane % 32) / 2, smp = lane % 2;
     const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
@@ -1013,6 +1013,16 @@ static size_t h16_lds_bytes(bool tree, const DevTree& T) {
 }
 
 hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum, int solo_sum);   // rt_kernels.hip
+
+// the pilot pass alone (rt_split_balanced): per tile 4 x the bounces of its pilot samples
+hipError_t launch_pilot_h(const RenderArgs& A, bool tree, int* cost, hipStream_t st) {
+    if (A.n_local_tiles <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((A.n_local_tiles + 7) / 8);                 // a wave covers two tiles
+    const size_t lds = h16_lds_bytes(tree, A.tree);
+    if (tree) hipLaunchKernelGGL((h16::k_tile_cost_h<true>), dim3(blocks), dim3(256), lds, st, A, cost, (unsigned char*)nullptr);
+    else hipLaunchKernelGGL((h16::k_tile_cost_h<false>), dim3(blocks), dim3(256), lds, st, A, cost, (unsigned char*)nullptr);
+    return hipGetLastError();
+}
 
 // the scheduling pre-pass of a binary16 render: pilot pass in binary16, then the precision-independent selection and ordering
 hipError_t launch_tile_order_h(const RenderArgs& A, bool tree, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st) {

@@ -1,8 +1,10 @@
 // rt_multi.hip — one frame over the GPUs of a node: rt_multi_render (include/rt_amd.h).
 //
 // No reference counterpart (the reference is single-GPU); the launch surface it extends is main.cu:422-427.  One process per
-// GPU.  The frame's 8x8 tiles (the reference's block shape, main.cu:351-352) are dealt round-robin in runs of RT_PART_RUN
-// consecutive tiles (rt_partition, rt_amd.h), so cheap sky tiles and expensive ground tiles mix on every GPU; pixels are independent (the per-pixel RNG is keyed by the
+// GPU.  The frame's 8x8 tiles (the reference's block shape, main.cu:351-352) are split over the ranks — by default into horizontal
+// bands of equal predicted cost (rt_split_balanced: every rank runs the same pilot pass over the whole frame and cuts it the same
+// way, no communication; a GPU's rays then meet the same part of the scene, as in the undivided frame), or dealt round-robin in
+// runs of RT_PART_RUN consecutive tiles (RT_SPLIT_RUNS); pixels are independent (the per-pixel RNG is keyed by the
 // absolute pixel_index, main.cu:93), so every split gives the bits of the single-GPU frame.  Each rank renders its tiles
 // into a compact tile-major buffer (rt_partition) and ONE exchange brings the buffers to the root: with RCCL a single
 // ncclGroupStart / ncclRecv x (nranks-1) | ncclSend / ncclGroupEnd straight out of the render buffer and straight into the
@@ -17,6 +19,7 @@
 #include <new>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include "../../include/rt_amd.h"
 #include "rt_handles.h"
 
@@ -71,6 +74,9 @@ struct rt_multi {
     void* d_local = nullptr; size_t local_bytes = 0;
     void* d_parts = nullptr; size_t parts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false;
+    // how the frame is divided (rt_multi_set_split) and the bands of the last balanced split, with what they were computed for
+    int split_mode = RT_SPLIT_RUNS;
+    int64_t starts[rt::kMaxSplitParts + 1] = {0}; bool have_split = false; uint64_t split_key[4] = {0, 0, 0, 0};
 };
 
 static int grow(void** p, size_t* have, size_t need) {
@@ -151,17 +157,38 @@ int rt_multi_destroy(rt_multi* M) {
     return rc;
 }
 
-// buffers for frames of this size (rt_multi_render grows them on demand; call this once before timing or graph capture)
+int rt_multi_set_split(rt_multi* M, int mode) {
+    if (!M || mode < RT_SPLIT_RUNS || mode > RT_SPLIT_BALANCED_CACHED) return RT_EINVAL;
+    M->split_mode = mode; M->have_split = false;
+    return 0;
+}
+int rt_multi_last_split(rt_multi* M, int64_t* starts) {
+    if (!M || !starts || !M->have_split) return RT_EINVAL;
+    for (int p = 0; p <= M->nranks; ++p) starts[p] = M->starts[p];
+    return 0;
+}
+
+// this rank's buffers for a part of n_mine pixels, the root's staging slots of `per` pixels each
+static int multi_buffers(rt_multi* M, int64_t n_mine, int64_t per, size_t px, int root) {
+    int rc = grow(&M->d_rand, &M->rand_bytes, (size_t)(n_mine > 0 ? n_mine : 1) * sizeof(rt_rand_state));
+    if (!rc && M->rank == root) rc = grow(&M->d_parts, &M->parts_bytes, (size_t)per * px * (size_t)M->nranks);
+    if (!rc && M->rank != root) rc = grow(&M->d_local, &M->local_bytes, (size_t)(n_mine > 0 ? n_mine : 1) * px);
+    return rc;
+}
+
+// buffers for frames of this size (rt_multi_render grows them on demand; call this once before timing or graph capture).
+// RT_SPLIT_RUNS: exactly what the frame needs.  Balanced splits: the bands' sizes depend on the scene — reserved here for bands of up to
+// twice the mean; a frame whose split asks for more grows them in rt_multi_render.
 int rt_multi_reserve(rt_multi* M, int max_x, int max_y, int precision, int root) {
     if (!M || max_x <= 0 || max_y <= 0 || root < 0 || root >= M->nranks) return RT_EINVAL;
     if (precision != RT_PRECISION_FP32 && precision != RT_PRECISION_FP16) return RT_EINVAL;
     const size_t px = precision == RT_PRECISION_FP16 ? 6 : 12;
-    const rt_partition mine = {M->rank, M->nranks}, first = {0, M->nranks};
-    const int64_t n_mine = rt_part_pixels(max_x, max_y, mine), per = rt_part_pixels(max_x, max_y, first);
-    int rc = grow(&M->d_rand, &M->rand_bytes, (size_t)(n_mine > 0 ? n_mine : 1) * sizeof(rt_rand_state));
-    if (!rc && M->rank == root) rc = grow(&M->d_parts, &M->parts_bytes, (size_t)per * px * (size_t)M->nranks);
-    if (!rc && M->rank != root) rc = grow(&M->d_local, &M->local_bytes, (size_t)per * px);
-    if (!rc) rc = rt_render_ctx_reserve(M->ctx, max_x, max_y, mine);
+    const rt_partition mine = {M->rank, M->nranks, 0, 0}, first = {0, M->nranks, 0, 0};
+    int64_t n_mine = rt_part_pixels(max_x, max_y, mine), per = rt_part_pixels(max_x, max_y, first);
+    const bool balanced = M->split_mode != RT_SPLIT_RUNS && M->nranks > 1;
+    if (balanced) { n_mine = per * 2; per = per * 2; }
+    int rc = multi_buffers(M, n_mine, per, px, root);
+    if (!rc) rc = rt_render_ctx_reserve(M->ctx, max_x, max_y, balanced ? rt_partition{0, 1, 0, 0} : mine);      // (a balanced split runs its pilot pass over the whole frame)
     return rc;
 }
 
@@ -171,17 +198,35 @@ int rt_multi_render(rt_multi* M, void* fb_full, int max_x, int max_y, int ns, co
     // the buffers, the RCCL datatype and rt_assemble are sized by `precision`, the render kernel by the world's: they must agree
     // (an fp32 world rendered into binary16-sized buffers would write out of bounds)
     if (precision != world->precision) return RT_EINVAL;
-    int rc = rt_multi_reserve(M, max_x, max_y, precision, root);
-    if (rc) return rc;
     const hipStream_t st = (hipStream_t)stream;
     const size_t px = precision == RT_PRECISION_FP16 ? 6 : 12;
-    const rt_partition mine = {M->rank, M->nranks}, first = {0, M->nranks};
-    const int64_t per = rt_part_pixels(max_x, max_y, first);
+    const int64_t tiles = (int64_t)((max_x + 7) / 8) * ((max_y + 7) / 8);
+    const bool balanced = M->split_mode != RT_SPLIT_RUNS && M->nranks > 1 && tiles >= M->nranks;
+    int rc = 0;
+    rt_partition mine = {M->rank, M->nranks, 0, 0};
+    int64_t per = 0;
+    RT_TRY(hipEventRecord(M->ev0, st));                                   // (this rank's share of the frame starts with the split)
+    if (balanced) {
+        // every rank cuts the frame the same way: the same pilot pass, the same integer arithmetic (rt_split_balanced)
+        const uint64_t key[4] = {world->serial, d_octree ? d_octree->serial : 0, ((uint64_t)(uint32_t)max_x << 32) | (uint32_t)max_y,
+                                 ((uint64_t)(uint32_t)M->nranks << 32) | (uint32_t)(d_octree ? d_octree->traversal : 0)};
+        if (!(M->split_mode == RT_SPLIT_BALANCED_CACHED && M->have_split && memcmp(key, M->split_key, sizeof(key)) == 0)) {
+            M->have_split = false;
+            if ((rc = rt_split_balanced(M->ctx, world, d_octree, max_x, max_y, M->nranks, M->starts, nullptr, nullptr, nullptr, stream))) return rc;
+            memcpy(M->split_key, key, sizeof(key)); M->have_split = true;
+        }
+        mine.tile_begin = M->starts[M->rank]; mine.tile_end = M->starts[M->rank + 1];
+        for (int r = 0; r < M->nranks; ++r) per = std::max<int64_t>(per, (M->starts[r + 1] - M->starts[r]) * 64);
+        if ((rc = multi_buffers(M, (mine.tile_end - mine.tile_begin) * 64, per, px, root))) return rc;
+    } else {
+        M->have_split = false;
+        if ((rc = rt_multi_reserve(M, max_x, max_y, precision, root))) return rc;
+        per = rt_part_pixels(max_x, max_y, rt_partition{0, M->nranks, 0, 0});
+    }
     const size_t stride = (size_t)per * px;
     // the root renders straight into its slot of the staging buffer, the others into their send buffer; a single rank's
     // "part" is the whole frame in the reference's row-major layout (rt_partition, nparts == 1): straight into fb_full
     void* local = M->nranks == 1 ? fb_full : M->rank == root ? (void*)((char*)M->d_parts + stride * (size_t)root) : M->d_local;
-    RT_TRY(hipEventRecord(M->ev0, st));
     if ((rc = rt_render_init(max_x, max_y, (rt_rand_state*)M->d_rand, mine, stream))) return rc;
     if ((rc = rt_render_on(M->ctx, local, max_x, max_y, ns, world, (rt_rand_state*)M->d_rand, d_octree, mine, stream))) return rc;
     RT_TRY(hipEventRecord(M->ev1, st));
@@ -197,7 +242,7 @@ int rt_multi_render(rt_multi* M, void* fb_full, int max_x, int max_y, int ns, co
             if (M->rank == root) {
                 for (int r = 0; r < M->nranks; ++r) {
                     if (r == root) continue;
-                    const rt_partition pr = {r, M->nranks};
+                    const rt_partition pr = {r, M->nranks, balanced ? M->starts[r] : 0, balanced ? M->starts[r + 1] : 0};
                     const size_t count = (size_t)rt_part_pixels(max_x, max_y, pr) * 3;
                     if (count && R.Recv((char*)M->d_parts + stride * (size_t)r, count, dtype, r, M->comm, st) != 0) { (void)R.GroupEnd(); return RT_ECOMM; }
                 }
@@ -207,7 +252,9 @@ int rt_multi_render(rt_multi* M, void* fb_full, int max_x, int max_y, int ns, co
             RT_NCCL(R.GroupEnd());
         }
     }
-    if (M->rank == root && M->nranks > 1) rc = rt_assemble(fb_full, M->d_parts, max_x, max_y, M->nranks, precision, stream);
+    if (M->rank == root && M->nranks > 1)
+        rc = balanced ? rt_assemble_split(fb_full, M->d_parts, max_x, max_y, M->nranks, M->starts, per, precision, stream)
+                      : rt_assemble(fb_full, M->d_parts, max_x, max_y, M->nranks, precision, stream);
     return rc;
 }
 

@@ -76,6 +76,18 @@
 #define RT_PROG_OWN 64          // render_progressive: pixel slots a wave owns before it takes chunks of 64 from the counter.  C3, ms per pass: 0: 0.645, 64: 0.567, 128: 0.611 (one request per lane and pixel: 1.05)
 #endif
 
+// ---- the balanced split of a frame over GPUs (rt_split_balanced) ---------------------------------------------------------------
+// A tile's predicted cost = RT_SPLIT_WB x (bounces of its 32 pilot samples) + RT_SPLIT_WT x (grid entries their walks pooled) + RT_SPLIT_WC x (grid columns they stepped through).
+#ifndef RT_SPLIT_WB
+#define RT_SPLIT_WB 1000
+#endif
+#ifndef RT_SPLIT_WT
+#define RT_SPLIT_WT 17
+#endif
+#ifndef RT_SPLIT_WC
+#define RT_SPLIT_WC 0
+#endif
+
 // ---- the pooled walks -----------------------------------------------------------------------------------
 #ifndef RT_QUORUM_SPARSE
 #define RT_QUORUM_SPARSE 4      // walk_pool returns when 1/4 of the walkers that entered are left.  C3: off 21.06 ms, 2: 20.14, 3: 19.91, 4: 19.94, 8: 20.41

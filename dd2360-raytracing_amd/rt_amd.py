@@ -35,7 +35,9 @@ class RtError(RuntimeError):
 
 
 class Partition(C.Structure):
-    _fields_ = [("part", C.c_int32), ("nparts", C.c_int32)]
+    """rt_partition: part `part` of `nparts`; tile_end > tile_begin: the tile range [tile_begin, tile_end) (a band of rt_split_balanced),
+    otherwise runs of PART_RUN tiles dealt round-robin"""
+    _fields_ = [("part", C.c_int32), ("nparts", C.c_int32), ("tile_begin", C.c_int64), ("tile_end", C.c_int64)]
 
 
 WHOLE = Partition(0, 1)
@@ -91,6 +93,10 @@ SYMBOLS = {
     "rt_multi_last_render_ms": (_i, [_vp, _vp, _vp]),
     "rt_multi_selftest": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "rt_assemble": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rt_assemble_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "rt_split_balanced": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rt_multi_set_split": (_i, [_vp, _i]),
+    "rt_multi_last_split": (_i, [_vp, _vp]),
     "rt_trace_rays": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _i, _i, _vp, _i]),
     "rt_format_ppm": (_i64, [_i, _i, _vp, _i, _vp, _i64]),
@@ -194,6 +200,7 @@ class RenderCtx:
             pass
 
 
+SPLIT_RUNS, SPLIT_BALANCED, SPLIT_BALANCED_CACHED = 0, 1, 2      # rt_multi_set_split
 GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 MULTI_ID_BYTES = 128
 
@@ -224,6 +231,7 @@ class Multi:
             self._id = C.create_string_buffer(unique_id, MULTI_ID_BYTES)
             check(lib().rt_multi_init(C.byref(h), rank, nranks, self._id), "rt_multi_init")
         self.h, self.rank, self.nranks = h, rank, nranks
+        self.split_mode = SPLIT_RUNS                             # the library's default (rt_multi_set_split)
 
     def reserve(self, max_x, max_y, precision=FP32, root=0):
         check(lib().rt_multi_reserve(self.h, max_x, max_y, precision, root), "rt_multi_reserve")
@@ -233,6 +241,16 @@ class Multi:
         check(lib().rt_multi_render(self.h, _dev(fb_full) if fb_full is not None else None, max_x, max_y, ns, world.h,
                                     octree.h if octree is not None else None, world.precision if precision is None else precision,
                                     root, _stream()), "rt_multi_render")
+
+    def set_split(self, mode):
+        check(lib().rt_multi_set_split(self.h, mode), "rt_multi_set_split")
+        self.split_mode = mode
+        return self
+
+    def last_split(self):
+        st = (C.c_int64 * (self.nranks + 1))()
+        check(lib().rt_multi_last_split(self.h, st), "rt_multi_last_split")
+        return list(st)
 
     def last_render_ms(self):
         a, b = C.c_float(0), C.c_float(0)
@@ -258,6 +276,32 @@ def device_check():
     n = C.c_int(0)
     rc = lib().rt_device_check(C.byref(n))
     return rc, n.value
+
+
+def split_balanced(world, octree, max_x, max_y, nparts, counts=False):
+    """rt_split_balanced: starts[nparts + 1] of the bands of equal predicted cost (and, counts=True, the pilot's per-tile bounces, tests and columns)"""
+    import numpy as np
+    tiles = ((max_x + 7) // 8) * ((max_y + 7) // 8)
+    st = (C.c_int64 * (nparts + 1))()
+    b = np.zeros(tiles, np.int32) if counts else None
+    t = np.zeros(tiles, np.int32) if counts else None
+    c = np.zeros(tiles, np.int32) if counts else None
+    check(lib().rt_split_balanced(None, world.h, octree.h if octree is not None else None, max_x, max_y, nparts, st,
+                                  b.ctypes.data_as(C.c_void_p) if counts else None, t.ctypes.data_as(C.c_void_p) if counts else None,
+                                  c.ctypes.data_as(C.c_void_p) if counts else None, _stream()), "rt_split_balanced")
+    return (list(st), b, t, c) if counts else list(st)
+
+
+def split_parts(starts):
+    """the rt_partition of every band of a split"""
+    n = len(starts) - 1
+    return [Partition(p, n, starts[p], starts[p + 1]) for p in range(n)]
+
+
+def assemble_split(fb_full, fb_parts, max_x, max_y, starts, part_stride_px, precision=FP32):
+    n = len(starts) - 1
+    st = (C.c_int64 * (n + 1))(*starts)
+    check(lib().rt_assemble_split(_dev(fb_full), _dev(fb_parts), max_x, max_y, n, st, part_stride_px, precision, _stream()), "rt_assemble_split")
 
 
 def part_pixels(max_x, max_y, part=WHOLE):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define RT_EINVAL (-1)
@@ -89,18 +89,21 @@ typedef struct rt_world rt_world;   /* device-resident scene: what d_list / d_wo
 typedef struct rt_octree rt_octree; /* Octree (acceleration_structure.h:57-62): host reference layout + device traversal copy */
 
 /* Which pixel tiles of the frame this call covers.  The frame is cut into 8x8-pixel tiles (the reference's
- * block shape, main.cu:351-352), numbered row-major from the bottom-left, and the tiles are dealt to the parts in runs of
- * RT_PART_RUN consecutive tiles: tile t lies in run r = t / RT_PART_RUN, run r belongs to part (r % nparts) and is that part's
- * (r / nparts)-th run.  (Runs rather than single tiles: the tiles a GPU renders side by side are neighbours in the image, as in
- * the undivided frame — their rays meet the same spheres.  C5, the slowest of 8 parts on one MI355X: single tiles 106-110 ms,
- * runs of 16: 104-110, of 64: 100-102, of 128: 101; whole frame / 8 = 83.)
- * nparts == 1: the whole frame, buffers in the reference's row-major layout (pixel_index = j*max_x + i).
- * nparts  > 1: buffers are tile-major and compact: element (local_tile*64 + ly*8 + lx),
- *              local_tile = (r / nparts) * RT_PART_RUN + t % RT_PART_RUN.  Part 0 never has fewer tiles than another part.
+ * block shape, main.cu:351-352), numbered row-major from the bottom-left.  Two forms of a part:
+ *  - a RANGE (tile_end > tile_begin): the consecutive tiles [tile_begin, tile_end) — a horizontal band of the image.
+ *    rt_split_balanced cuts a frame into nparts such bands of equal predicted cost (what rt_multi_render renders by default);
+ *    local tile = tile - tile_begin.
+ *  - RUNS (tile_begin == tile_end == 0): tiles dealt to the parts in runs of RT_PART_RUN consecutive tiles: tile t lies in run
+ *    r = t / RT_PART_RUN, run r belongs to part (r % nparts) and is that part's (r / nparts)-th run;
+ *    local tile = (r / nparts) * RT_PART_RUN + t % RT_PART_RUN.  Part 0 never has fewer tiles than another part.
+ *    (C5, the slowest of 8 parts on one MI355X: single tiles 106-110 ms, runs of 64: 100-102; whole frame / 8 = 83.)
+ * nparts == 1 without a range: the whole frame, buffers in the reference's row-major layout (pixel_index = j*max_x + i).
+ * Otherwise buffers are tile-major and compact: element (local_tile*64 + ly*8 + lx).
  * rt_part_pixels() gives the element count of such a buffer. */
 #define RT_PART_RUN 64
 typedef struct rt_partition {
     int32_t part, nparts;
+    int64_t tile_begin, tile_end;
 } rt_partition;
 
 /* ---- library ---------------------------------------------------------------------------------------------- */
@@ -237,11 +240,29 @@ int rt_render_ctx_counters(rt_render_ctx* ctx, uint32_t* out4);
  * rt_part_pixels(max_x,max_y,{0,nparts}) elements (the layout an all-gather of the parts produces). */
 int rt_assemble(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, int precision, void* stream);
 
+/* A frame cut into nparts horizontal bands of equal PREDICTED COST (no reference counterpart; extends the launch surface main.cu:422-427).
+ * A pilot pass over the whole frame — two one-sample paths per 2x2 pixel block on a private RNG stream, the scheduling pre-pass of
+ * rt_render — counts per tile the bounces, the grid entries its paths' walks had to test and the grid columns they stepped through; a tile's
+ * cost is a fixed linear form of the three (rt_tuning.h, calibrated on measured band times), and the cuts fall where the running cost passes k/nparts of the total.
+ * Integer arithmetic on counts that every GPU of the same kind reproduces bit for bit: every rank of a job computes the same
+ * starts[] without talking to the others.  starts[0] = 0 <= ... <= starts[nparts] = number of tiles; part p is
+ * rt_partition{p, nparts, starts[p], starts[p+1]} (never empty: RT_EINVAL when the frame has fewer tiles than parts).
+ * Why bands: a GPU's rays meet the same part of the scene, as in the undivided frame (runs dealt round-robin keep the whole scene's
+ * working set on every GPU for an eighth of the rays).  tile_bounces / tile_tests / tile_columns (host, [tiles], may be NULL) receive the pilot's counts.
+ * Synchronises with `stream`.  ctx NULL = the world's own context. */
+int rt_split_balanced(rt_render_ctx* ctx, const rt_world* world, const rt_octree* d_octree, int max_x, int max_y, int nparts,
+                      int64_t* starts /* [nparts + 1] */, int32_t* tile_bounces, int32_t* tile_tests, int32_t* tile_columns, void* stream);
+/* rt_assemble for such a split: band p's buffer begins part_stride_px elements behind band p-1's (>= the largest band). */
+int rt_assemble_split(void* fb_full, const void* fb_parts, int max_x, int max_y, int nparts, const int64_t* starts, int64_t part_stride_px,
+                      int precision, void* stream);
+
 /* ---- multi-GPU: one frame over the GPUs of one node, one process per GPU -------------------------------------------------
- * No reference counterpart (the reference is single-GPU, launch surface main.cu:422-427).  Rank r of nranks renders the tiles
- * t with t % nranks == r (rt_partition{r, nranks}) of every frame; ONE exchange brings the compact part buffers to the root
- * (RCCL over xGMI: one ncclGroupStart / ncclRecv x (nranks-1) | ncclSend / ncclGroupEnd, straight from the render buffer
- * into the root's staging slots, on the caller's stream), where rt_assemble writes the row-major frame into fb_full.
+ * No reference counterpart (the reference is single-GPU, launch surface main.cu:422-427).  Every rank computes the same split of
+ * the frame's tiles (default RT_SPLIT_BALANCED: rt_split_balanced's bands, recomputed for every frame; RT_SPLIT_RUNS: runs of
+ * RT_PART_RUN tiles dealt round-robin, no pilot pass over the whole frame), renders its part into a compact tile-major buffer, and
+ * ONE exchange brings the parts to the root (RCCL over xGMI: one ncclGroupStart / ncclRecv x (nranks-1) | ncclSend / ncclGroupEnd,
+ * straight from the render buffer into the root's staging slots, on the caller's stream), where rt_assemble / rt_assemble_split
+ * writes the row-major frame into fb_full.
  * rt_multi_unique_id: rank 0 creates the 128-byte RCCL id and hands it to the other ranks by any means (a file, MPI,
  * torch.distributed over gloo); rt_multi_init: ncclCommInitRank on the calling process's current device.  RCCL is bound at
  * run time (dlopen): RT_ENOTSUP when it is absent. */
@@ -260,6 +281,13 @@ int rt_multi_probe(void);
 typedef int (*rt_gather_fn)(void* user, const void* d_send, size_t send_bytes, void* d_parts, size_t part_stride_bytes, int root, void* stream);
 int rt_multi_init_custom(rt_multi** out, int rank, int nranks, rt_gather_fn gather, void* user);
 int rt_multi_destroy(rt_multi* m);
+/* how rt_multi_render divides the frame (the same on every rank): */
+#define RT_SPLIT_RUNS 0             /* runs of RT_PART_RUN tiles, round-robin */
+#define RT_SPLIT_BALANCED 1         /* bands of equal predicted cost, from a pilot pass over the whole frame on every rank, every frame (default) */
+#define RT_SPLIT_BALANCED_CACHED 2  /* ... kept while world, tree, frame size stay the same (a static scene rendered again and again) */
+int rt_multi_set_split(rt_multi* m, int mode);
+/* the split of the last rt_multi_render: starts[nranks + 1] (RT_SPLIT_RUNS: RT_EINVAL) */
+int rt_multi_last_split(rt_multi* m, int64_t* starts);
 /* buffers for frames of this size now (otherwise the first rt_multi_render of a larger frame allocates) */
 int rt_multi_reserve(rt_multi* m, int max_x, int max_y, int precision, int root);
 /* render_init + render of this rank's tiles, the exchange, and on the root the assembled frame in fb_full (device buffer of

@@ -46,21 +46,25 @@ def test_multi_render_one_rank_over_rccl(rt, cuda):
     M.close()
 
 
-@pytest.mark.parametrize("world,nx,ny,ns,n,spl,fp16", [
-    (2, 400, 232, 16, 10000, 32, 0),         # octree, long-chain classification on
-    (3, 203, 117, 4, 500, 0, 0),             # ragged frame, three ranks, hitable_list path
-    (2, 200, 120, 4, 500, 30, 1),            # USE_FP16
+@pytest.mark.parametrize("world,nx,ny,ns,n,spl,fp16,split", [
+    (2, 400, 232, 16, 10000, 32, 0, 1),      # octree, long-chain classification on; bands of equal predicted cost (the default split)
+    (3, 203, 117, 4, 500, 0, 0, 1),          # ragged frame, three ranks, hitable_list path
+    (2, 200, 120, 4, 500, 30, 1, 1),         # USE_FP16
+    (2, 400, 232, 16, 10000, 32, 0, 0),      # the same three through runs of RT_PART_RUN tiles dealt round-robin (RT_SPLIT_RUNS)
+    (3, 203, 117, 4, 500, 0, 0, 0),
+    (2, 200, 120, 4, 500, 30, 1, 0),
+    (3, 400, 232, 16, 10000, 32, 0, 2),      # the split kept from the first frame to the second (RT_SPLIT_BALANCED_CACHED)
 ])
-def test_multi_render_child_processes_on_one_gpu(rt, cuda, world, nx, ny, ns, n, spl, fp16):
-    """N fresh child processes, one rank each, all on GPU 0: the real rt_multi_render (partition, render, staging slots,
-    rt_assemble) with a gloo exchange; rank 0 checks the assembled frame against a single-process render bit for bit."""
+def test_multi_render_child_processes_on_one_gpu(rt, cuda, world, nx, ny, ns, n, spl, fp16, split):
+    """N fresh child processes, one rank each, all on GPU 0: the real rt_multi_render (split, render, staging slots,
+    rt_assemble / rt_assemble_split) with a gloo exchange; rank 0 checks the assembled frame against a single-process render bit for bit."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(ROOT, "tests", "multi_worker.py")
     args = [str(v) for v in (world, port, nx, ny, ns, n, spl, fp16)]
-    procs = [subprocess.Popen([sys.executable, script, str(r)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, script, str(r)] + args + [str(split)], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
     outs = []
     try:
         for p in procs:

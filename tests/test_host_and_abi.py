@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol(rt):
     L = rt.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 5
+    assert L.rt_abi_version() == 6
 
 
 def test_pod_sizes_match_reference_structs(rt):
@@ -39,6 +39,30 @@ def test_compute_calls_reject_bad_arguments(rt):
     assert L.rt_part_pixels(8, 8, rt.Partition(3, 2)) == -1
     assert L.rt_create_world(None, 4, 0.1, None, 1, 1, None, 0, None) == -1
     assert rt.lib().rt_error_string(-1) == b"invalid argument"
+
+
+def test_range_partitions_the_bands_of_a_balanced_split(rt):
+    """rt_partition with a tile range (ABI 6): a band [tile_begin, tile_end) of the row-major tile numbering — element counts, argument
+    checks, and the runs form (tile_begin == tile_end == 0) unchanged next to it."""
+    L = rt.lib()
+    nx, ny = 100, 50                                              # 13 x 7 = 91 tiles, ragged edges
+    tiles = 13 * 7
+    assert rt.part_pixels(nx, ny, rt.Partition(0, 1, 0, tiles)) == tiles * 64          # a range is always compact and tile-major ...
+    assert rt.part_pixels(nx, ny, rt.Partition(0, 1)) == nx * ny                       # ... the undivided frame is row-major
+    starts = [0, 10, 11, 60, tiles]
+    parts = rt.split_parts(starts)
+    assert [(p.part, p.nparts, p.tile_begin, p.tile_end) for p in parts] == [(0, 4, 0, 10), (1, 4, 10, 11), (2, 4, 11, 60), (3, 4, 60, tiles)]
+    assert [rt.part_pixels(nx, ny, p) for p in parts] == [640, 64, 49 * 64, 31 * 64]
+    assert L.rt_part_pixels(nx, ny, rt.Partition(0, 2, 5, 5)) == -1                    # an empty range that is not (0, 0)
+    assert L.rt_part_pixels(nx, ny, rt.Partition(0, 2, 7, 3)) == -1
+    assert L.rt_part_pixels(nx, ny, rt.Partition(0, 2, -1, 3)) == -1
+    assert L.rt_part_pixels(nx, ny, rt.Partition(1, 2, 60, tiles + 1)) == -1          # past the frame's last tile
+    assert L.rt_render_init(nx, ny, None, rt.Partition(1, 2, 60, tiles + 1), None) == -1
+    # split entry points check their arguments without a device
+    st = (__import__("ctypes").c_int64 * 3)(0, 40, tiles)
+    assert L.rt_assemble_split(None, None, nx, ny, 2, st, 64 * 51, 0, None) == -1
+    assert L.rt_split_balanced(None, None, None, nx, ny, 2, st, None, None, None, None) == -1
+    assert L.rt_multi_set_split(None, 1) == -1 and L.rt_multi_last_split(None, st) == -1
 
 
 @pytest.mark.parametrize("precision", [0, 1])
