@@ -117,7 +117,7 @@ def parse_pmc_dir(d):
     return {c: acc[c] / max(1, len(disp[c])) for c in acc}
 
 
-def collect_pmc(config, list_reference, timeout=240):
+def collect_pmc(config, list_reference, arith="ieee", timeout=240, deadline=None):
     """rocprofv3 --pmc passes over a short run of this same script (child processes, before this process touches the GPU).
     Returns ({counter: per-dispatch average for the render kernel}, note).  Counters come in their own runs, never together
     with tracing; the profiled program stands directly behind `--`."""
@@ -132,11 +132,14 @@ def collect_pmc(config, list_reference, timeout=240):
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"]
     if list_reference:
         child.append("--list-reference")
-    if "--arith" in sys.argv:
-        child += ["--arith", sys.argv[sys.argv.index("--arith") + 1]]
+    if arith != "ieee":
+        child += ["--arith", arith]                          # (the parsed value: `--arith=contract` and prefixes profile the right kernels too)
     note = None
     try:
         for i, pmc in enumerate(PMC_PASSES):
+            if deadline is not None and time.monotonic() + timeout > deadline:
+                note = "pmc passes %d.. skipped: the job's --timeout leaves no room for them" % i      # optional extras never cost the result line
+                break
             d = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc"] + pmc.split() + ["--output-format", "csv", "-d", d, "--"] + child
             try:
@@ -151,6 +154,31 @@ def collect_pmc(config, list_reference, timeout=240):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out, note
+
+
+def alive(pid):
+    try:
+        return open("/proc/%d/stat" % pid).read().rsplit(")", 1)[1].split()[0] != "Z"      # a zombie is not a survivor
+    except (FileNotFoundError, ProcessLookupError, IndexError):
+        return False
+
+
+def descendants(root):
+    """pids of every process below `root` right now (children of children included), from /proc — never root itself"""
+    parent = {}
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                parent[int(d)] = int(open("/proc/%s/stat" % d).read().rsplit(")", 1)[1].split()[1])
+            except (FileNotFoundError, ProcessLookupError, IndexError, ValueError):
+                pass
+    out, frontier = [], [root]
+    while frontier:
+        cur = frontier.pop()
+        for pid, pp in parent.items():
+            if pp == cur and pid != root and pid not in out:
+                out.append(pid); frontier.append(pid)
+    return out
 
 
 def self_launch(n, argv, timeout):
@@ -179,17 +207,40 @@ def self_launch(n, argv, timeout):
     try:
         rc = p.wait(timeout=timeout)
     except subprocess.TimeoutExpired:
-        print("bench.py: the %d-rank job did not finish within %d s — killing its process group" % (n, timeout), file=sys.stderr, flush=True)
-        for sig in (signal.SIGTERM, signal.SIGKILL):
+        print("bench.py: the %d-rank job did not finish within %d s — stopping it" % (n, timeout), file=sys.stderr, flush=True)
+        # p is the elastic agent, alone in the group started above: it starts every rank in a session of its OWN
+        # (start_new_session), so signalling p's group reaches the agent only.  The ranks are recorded by pid first (the
+        # descendants of p, from /proc), the agent gets SIGTERM and its own 30 s grace to stop them, and whatever of the
+        # recorded pids is still alive afterwards is killed — those exact processes and their sessions, nothing else.
+        ranks = descendants(p.pid)
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        try:
+            p.wait(timeout=40)
+        except subprocess.TimeoutExpired:
             try:
-                os.killpg(p.pid, sig)                              # exactly the group started above
+                os.killpg(p.pid, signal.SIGKILL)
             except ProcessLookupError:
-                break
-            try:
-                p.wait(timeout=10)
-                break
-            except subprocess.TimeoutExpired:
-                continue
+                pass
+        deadline = time.monotonic() + 5
+        for pid in ranks:
+            while alive(pid) and time.monotonic() < deadline:
+                time.sleep(0.1)
+            if alive(pid):
+                print("bench.py: rank process %d survived the agent — killing it" % pid, file=sys.stderr, flush=True)
+                try:
+                    os.killpg(os.getpgid(pid), signal.SIGKILL)     # its own session / group (torch.distributed.run made it the leader)
+                except (ProcessLookupError, PermissionError):
+                    try:
+                        os.kill(pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+        try:
+            p.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            pass
         rc = 124
     t.join(timeout=5)
     found = None
@@ -231,6 +282,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline_issue / traffic become null)")
     ap.add_argument("--list-reference", action="store_true", help="octree-off configs: plain list-order scan instead of the candidate grid")
     ap.add_argument("--arith", default="ieee", choices=["ieee", "contract"], help="contract: the opt-in tolerance mode with FMA contraction allowed (rt_world_set_arith) — never the parity mode, reported separately")
+    ap.add_argument("--split", default="runs", choices=["runs", "balanced", "balanced-cached"], help="N>1: how rt_multi_render divides the frame — runs of 64 tiles dealt round-robin (default), "
+                    "bands of equal predicted cost from a whole-frame pilot pass on every rank and frame, or those bands kept from frame to frame (rt_multi_set_split)")
     ap.add_argument("--timeout", type=int, default=900, help="N>1: seconds after which the job is killed (self-launched: by the parent; every rank also watches itself)")
     args = ap.parse_args()
 
@@ -244,7 +297,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without a launcher: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
     watchdog = arm_watchdog(args.timeout + (60 if os.environ.get("RT_BENCH_SELF_LAUNCHED") == "1" else 0), rank) if world > 1 else None
     if os.environ.get("RT_BENCH_TEST_HANG") == str(rank):          # tests/test_bench_launch.py: a rank that never arrives
-        watchdog.cancel()
+        if watchdog is not None:
+            watchdog.cancel()
         time.sleep(3600)
     weak = world > 1 and args.scaling == "weak"
     cfg_key = args.config or ("c3" if (world == 1 or weak) else "c5")
@@ -262,7 +316,9 @@ def main():
     # kernel time is its issue rate (the tile split deals the frame's work out evenly: per_rank_render_ms shows how evenly).
     pmc, pmc_note = ({}, "skipped")
     if not args.no_pmc and not weak and rank == 0:
-        pmc, pmc_note = collect_pmc(cfg_key, args.list_reference, timeout=240 if world == 1 else 400)
+        # (N > 1: the other ranks wait at the barrier below with their watchdogs armed: the passes get a third of --timeout at most)
+        pmc, pmc_note = collect_pmc(cfg_key, args.list_reference, args.arith, timeout=240 if world == 1 else 400,
+                                    deadline=None if world == 1 else time.monotonic() + args.timeout / 3.0)
     if world > 1:
         dist.barrier()
 
@@ -339,7 +395,10 @@ def main():
         if M is None:
             from multi_worker import make_gloo_gather
             transport = "gloo (host-staged) — %s" % why_not
-            M = rt.Multi(rank, world, gather=make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if cfg.get("fp16") else 12))
+            gather, holder = make_gloo_gather(rt, torch, dist, rank, world, nx, ny, 6 if cfg.get("fp16") else 12)
+            M = rt.Multi(rank, world, gather=gather)
+            holder["M"] = M
+        M.set_split({"runs": rt.SPLIT_RUNS, "balanced": rt.SPLIT_BALANCED, "balanced-cached": rt.SPLIT_BALANCED_CACHED}[args.split])
         M.reserve(nx, ny, precision, 0)
         full = torch.zeros(nx * ny * 3, dtype=torch.float16 if cfg.get("fp16") else torch.float32, device="cuda") if rank == 0 else None
     else:
@@ -395,7 +454,12 @@ def main():
         kernel_ms = sum(kt) / max(1, len(kt))
     long_chains = None if world > 1 else W.render_counters()["long_chains"]      # pixels the pilot pass started as long chains (last frame)
     samples_step = nx * ny * spp                                  # whole job, all ranks
-    local_samples = rt.part_pixels(nx, ny, rt.Partition(rank, world)) * spp if world > 1 else samples_step
+    if world > 1 and args.split != "runs":
+        stt = M.last_split()                                       # the bands of the last frame (every rank computed the same ones)
+        rank_pixels = [(stt[r + 1] - stt[r]) * 64 for r in range(world)]
+    else:
+        rank_pixels = [rt.part_pixels(nx, ny, rt.Partition(r, world)) for r in range(world)] if world > 1 else [nx * ny]
+    local_samples = rank_pixels[rank] * spp if world > 1 else samples_step
     value = samples_step * args.steps / dt / 1e6
 
     # strong scaling: the same frame on ONE GPU (rank 0 alone, after the timed region) as the reference point of the curve
@@ -426,7 +490,9 @@ def main():
             workload += "; ARITHMETIC: FMA contraction allowed (RT_ARITH_CONTRACT) - a tolerance mode, NOT the pixel-identical parity mode"
         if world > 1:
             workload += ("; frame grown to %d x 960000 px" % world if weak else "; the fixed frame") + \
-                        ", runs of 64 8x8 tiles round-robin over %d GPUs (rt_multi_render), one exchange to rank 0 over %s" % (world, transport)
+                        ", %s over %d GPUs (rt_multi_render), one exchange to rank 0 over %s" % (
+                            {"runs": "runs of 64 8x8 tiles round-robin", "balanced": "bands of equal predicted cost (rt_split_balanced: a whole-frame pilot pass on every rank, every frame, inside the timed region)",
+                             "balanced-cached": "bands of equal predicted cost, kept from the first frame on (rt_split_balanced once, outside the timed steps)"}[args.split], world, transport)
         out = {
             "metric": "Msamples/s (W*H*spp/render_time) at %dx%d, %d spheres" % (nx, ny, cfg["spheres"]),
             "value": round(value, 3), "unit": "Msamples/s",
@@ -447,6 +513,7 @@ def main():
                                  "work, not issued instructions, and can exceed a machine peak: roofline_issue is the machine-side figure."
                                  % ("" if world == 1 else ", this rank's share")},
         }
+        out["roofline"]["frac_reference_work"] = out["roofline"]["frac"]
         vi, tc = pmc.get("SQ_INSTS_VALU"), pmc.get("SQ_THREAD_CYCLES_VALU")
         if vi:
             share = local_samples / float(samples_step)           # N > 1: this rank's part of the profiled one-GPU frame
@@ -458,20 +525,30 @@ def main():
                 "peak_spec": round(PEAK_VALU_ISSUE_SPEC_G, 1), "frac_of_spec": round(rate / PEAK_VALU_ISSUE_SPEC_G, 4),
                 "valu_wave_insts_per_launch": int(vi * share),
                 "lane_utilisation": round(tc / (vi * 64.0), 4) if tc else None,
+                "lane_op_frac": round(rate / PEAK_VALU_ISSUE_SPEC_G * tc / (vi * 64.0), 4) if tc else None,
                 "salu_to_valu": round(pmc["SQ_INSTS_SALU"] / vi, 4) if pmc.get("SQ_INSTS_SALU") else None,
                 "wait_any_share": round(pmc["SQ_WAIT_ANY"] / wc, 4) if pmc.get("SQ_WAIT_ANY") and wc else None,
                 "wait_inst_share": round(pmc["SQ_WAIT_INST_ANY"] / wc, 4) if pmc.get("SQ_WAIT_INST_ANY") and wc else None,
                 "note": "rocprofv3 --pmc passes over 3 launches of this workload in child processes of this run (per-launch averages of the "
                         "render kernel); SQ_INSTS_VALU / kernel_ms.  `peak` is the issue rate an independent v_fma_f32 stream was MEASURED to sustain "
                         "on this chip (tools/micro/pk_rate.hip), `peak_spec` the spec sheet's 157.3 TFLOP/s / 128 flops per wave-instruction; "
-                        "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)" + ("; " + pmc_note if pmc_note else "")}
+                        "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU); lane_op_frac = frac_of_spec x lane_utilisation: busy lane-slots of the "
+                        "spec sheet's lane-slots — the one machine fraction that cannot exceed 1" + ("; " + pmc_note if pmc_note else "")}
             if world > 1:
                 out["roofline_issue"]["note"] += ("; N > 1: the counters are those of the SAME frame rendered on one GPU (rank 0, before the job touched "
                                                   "a GPU), a rank's instructions = its share of the frame's pixels (%.4f) of them, over its own kernel time" % share)
-                out["roofline_issue"]["per_rank_achieved"] = [round(vi * (rt.part_pixels(nx, ny, rt.Partition(r, world)) * spp / float(samples_step)) / (per_rank[r][1] * 1e-3) / 1e9, 2)
+                out["roofline_issue"]["per_rank_achieved"] = [round(vi * (rank_pixels[r] * spp / float(samples_step)) / (per_rank[r][1] * 1e-3) / 1e9, 2)
                                                               for r in range(world)]
         else:
             out["roofline_issue"] = {"note": "no counters: " + str(pmc_note)}
+        # A fraction above 1 is not a fraction.  Where the culling grid leaves the reference's visit set so far behind that its algorithmic
+        # figure exceeds the machine's peak (C5: 2 150 sphere tests per ray in the reference, 82 here), `frac` is the MACHINE fraction
+        # (lane_op_frac: busy VALU lane-slots of the peak's) and the algorithmic figure stays beside it as frac_reference_work.
+        if out["roofline"]["frac_reference_work"] > 1.0:
+            mf = out["roofline_issue"].get("lane_op_frac")
+            out["roofline"]["frac"] = mf
+            out["roofline"]["note"] += ("  HERE the algorithmic figure exceeds the peak (frac_reference_work %.3f): `frac` is roofline_issue.lane_op_frac%s, "
+                                        "`achieved` / `peak` still the algorithmic TFLOP/s against the spec sheet." % (out["roofline"]["frac_reference_work"], "" if mf is not None else " (null: no counter passes in this run)"))
         # the same kernel against the HBM roof (for the record: it is nowhere near it): algorithmic bytes = RNG state in + out
         # (2 x 48 B) and the vec3 written (12 B) per pixel this rank renders
         alg_bytes = (96.0 + (6.0 if cfg.get("fp16") else 12.0)) * (local_samples / spp)
@@ -496,7 +573,8 @@ def main():
         if single is not None:
             out["single_gpu_same_frame"] = single
             out["speedup_vs_single_gpu_same_frame"] = round(single["ms_per_step"] / (dt / args.steps * 1e3), 4)
-        if world == 1 and not args.no_cpu_baseline:
+            out["value_1gpu_same_workload"] = single["msamples_per_s"]      # the like-for-like reference point of `value` (the driver's N = 1 line is C3, another workload)
+        if not args.no_cpu_baseline:
             threads = usable_cores()
             # hitable_list is O(N) per ray: the sample is cut so that it stays ~10 s of wall time on any core count
             if cfg.get("fp16"):

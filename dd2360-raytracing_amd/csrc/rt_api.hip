@@ -268,6 +268,7 @@ static int ctx_reserve(rt_render_ctx& C, int64_t tiles) {
 // the same for the tile order a progressive sequence keeps (its own buffers: a render on the same context does not disturb it)
 static int ctx_reserve_progressive(rt_render_ctx& C, int64_t tiles) {
     if (C.p_tiles >= tiles) return 0;
+    if (C.p_pinned) return RT_EINVAL;        // a hipGraph replays passes that read these buffers: a larger frame needs a context of its own
     void* old[2] = {C.p_cost, C.p_order};
     C.p_cost = nullptr; C.p_order = nullptr; C.p_tiles = 0; C.p_valid = false;
     int rc = free_all(old, 2);
@@ -771,7 +772,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
             else RT_TRY(launch_tile_order(A, d_octree != nullptr, C.p_cost, C.p_order, nullptr, nullptr, st));
             memcpy(C.p_key, key, sizeof(key)); C.p_valid = true;
         }
-        if (C.p_valid && memcmp(C.p_key, key, sizeof(key)) == 0 && C.p_tiles >= A.n_local_tiles) A.order = C.p_order;
+        if (C.p_valid && memcmp(C.p_key, key, sizeof(key)) == 0 && C.p_tiles >= A.n_local_tiles) { A.order = C.p_order; if (cap) C.p_pinned = true; }
     }
     if (sched) {
         const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long

@@ -27,6 +27,7 @@ struct rt_render_ctx {
     // tile order of a progressive sequence (rt_render_progressive): the pilot pass that the call with current_sample == 1 runs, kept
     // in buffers of its own and reused by the following passes of the same frame (p_key: world and tree serials, frame size, partition)
     int* p_cost = nullptr; unsigned int* p_order = nullptr; int64_t p_tiles = 0; bool p_valid = false; uint64_t p_key[5] = {0, 0, 0, 0, 0};
+    bool p_pinned = false;      // a captured progressive pass has baked p_order's address into a hipGraph: the buffers are never freed or moved again
     // HIP events around the dominant kernel of each render call (ring of the last 64), see rt_render_ctx_times
     hipEvent_t ev0[64] = {}, ev1[64] = {}; unsigned ev_head = 0, ev_count = 0; bool ev_ready = false;
     // ordering of successive launches that share this context

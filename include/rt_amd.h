@@ -206,7 +206,9 @@ int rt_render_progressive(void* fb, int max_x, int max_y, int current_sample, co
  * but run one after the other; frames that should overlap on one GPU — two partitions of a frame on two streams — take a
  * context each and go through the *_on entry points.  A context first used inside a hipGraph capture must have been
  * prepared before (rt_render_ctx_reserve, or one uncaptured call of the same frame size — in either precision: the binary16
- * render has a pilot pass and a workspace too); timing events are not recorded during a capture. */
+ * render has a pilot pass and a workspace too); timing events are not recorded during a capture.  A captured rt_render_progressive pass
+ * bakes the context's tile-order buffer into the graph: from then on the context refuses (RT_EINVAL) a progressive sequence of a
+ * larger frame, which would have to move that buffer — give such a sequence a context of its own for the graph's lifetime. */
 int rt_render_ctx_create(rt_render_ctx** out);
 int rt_render_ctx_reserve(rt_render_ctx* ctx, int max_x, int max_y, rt_partition part);   /* workspace for frames of this size, now */
 int rt_render_ctx_destroy(rt_render_ctx* ctx);

@@ -40,8 +40,20 @@ def test_self_launch_relays_a_failing_job():
 def test_self_launch_kills_a_hung_job_at_the_timeout():
     rc, out, err, secs = _run(["--timeout", "20"], env={"RT_BENCH_TEST_HANG": "1"})
     assert rc == 124, (rc, err[-1500:])
-    assert "killing its process group" in err
+    assert "stopping it" in err
     assert secs < 90
+    # no rank is left behind: the hung rank slept in a session of its own (torch.distributed.run starts its workers that way), out of
+    # reach of a signal to the agent's group — the parent records the ranks' pids and kills what survives the agent
+    left = []
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                argv = open("/proc/%s/cmdline" % d, "rb").read().split(b"\0")
+            except OSError:
+                continue
+            if any(a.endswith(b"bench.py") for a in argv) and b"--timeout" in argv and b"20" in argv and open("/proc/%s/stat" % d).read().rsplit(")", 1)[1].split()[0] != "Z":
+                left.append((int(d), argv))
+    assert left == [], left
 
 
 def test_launcher_form_still_checks_world_size():

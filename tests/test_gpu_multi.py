@@ -116,7 +116,15 @@ def test_bench_self_launch_two_ranks_one_gpu(cuda):
     assert d["single_gpu_same_frame"]["frame_equals_multi_gpu_frame"] is True
     assert d["speedup_vs_single_gpu_same_frame"] > 0
     assert len(d["per_rank_render_ms"]["kernel"]) == 2 and d["per_rank_render_ms"]["imbalance_max_over_mean"] >= 1.0
-    assert d["roofline"]["frac"] > 0 and "roofline_issue" in d
+    assert "roofline_issue" in d
+    # a line that survives a SCALE run — a fraction that is one (C5's algorithmic figure exceeds the machine's peak: the
+    # machine fraction takes its place, the reference-visit-set figure stays beside it), the like-for-like one-GPU value at top
+    # level, and the CPU baseline on the N > 1 line too
+    assert 0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["frac_reference_work"] > 0
+    assert d["roofline"]["frac"] == d["roofline_issue"]["lane_op_frac"] or d["roofline"]["frac_reference_work"] <= 1.0
+    assert 0 < d["roofline_issue"]["lane_op_frac"] <= 1.0
+    assert d["value_1gpu_same_workload"] == d["single_gpu_same_frame"]["msamples_per_s"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
 
 
 def test_render_calls_on_two_streams(rt, cuda):

@@ -96,7 +96,7 @@ def pmc_pass(n, radius, spl, variant):
                                                        "--cell", "%d,%g,%d,%s" % (n, radius, spl, variant)]
         p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         if p.returncode != 0:
-            return {"error": "rc %d" % p.returncode}
+            return {"error": "rc %d" % p.returncode, "stderr_tail": p.stderr.decode(errors="replace")[-500:]}
         out = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
@@ -147,6 +147,14 @@ def run(sizes, radii, reps=REPS, verbose=True, image_dir=None, pmc=False):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from image_metrics import compare_frames
     cells = []
+    # the counter passes first, for every cell, while this process has not touched the GPU (World / Octree are host objects until
+    # they are uploaded): the profiled children then have the device to themselves, as bench.py's have
+    pmc_of = {}
+    if pmc:
+        for radius in radii:
+            for n in sizes:
+                _, _, spl = spl_for(rt, n, radius)
+                pmc_of[(radius, n)] = {"list": pmc_pass(n, radius, spl, "list"), "octree": pmc_pass(n, radius, spl, "octree")}
     for radius in radii:
         for n in sizes:
             torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
@@ -174,7 +182,7 @@ def run(sizes, radii, reps=REPS, verbose=True, image_dir=None, pmc=False):
             # the peak of the caller's buffers (RNG states, frame: the torch allocator's own peak — it caches freed blocks)
             c["device_memory_mb"] = round(max(0, free0 - free1) / 2.0 ** 20 + torch.cuda.max_memory_allocated() / 2.0 ** 20, 2)
             if pmc:
-                c["pmc"] = {"list": pmc_pass(n, radius, spl, "list"), "octree": pmc_pass(n, radius, spl, "octree")}
+                c["pmc"] = pmc_of[(radius, n)]
             cells.append(c)
             if verbose:
                 print("r=%.1f N=%5d SPL=%3d  list scan %8.3f ms  list via grid %7.3f ms  octree %7.3f ms  octree vs scan %6.2fx  Welch t = %s, df = %.1f, p = %.2e%s"
