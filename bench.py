@@ -137,13 +137,14 @@ def collect_pmc(config, list_reference, arith="ieee", timeout=240, deadline=None
     note = None
     try:
         for i, pmc in enumerate(PMC_PASSES):
-            if deadline is not None and time.monotonic() + timeout > deadline:
+            left = timeout if deadline is None else min(timeout, deadline - time.monotonic())
+            if left < 45:
                 note = "pmc passes %d.. skipped: the job's --timeout leaves no room for them" % i      # optional extras never cost the result line
                 break
             d = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc"] + pmc.split() + ["--output-format", "csv", "-d", d, "--"] + child
             try:
-                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
             except subprocess.TimeoutExpired:
                 note = "pmc pass %d timed out" % i
                 break
