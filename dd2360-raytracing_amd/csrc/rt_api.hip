@@ -742,7 +742,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
     A.tail_list = nullptr; A.f_tail = 0.f;
-    A.n_lanes = 0; A.f_inflight = tune_value("RT_F_INFLIGHT", RT_F_INFLIGHT); A.f_static = tune_value("RT_F_STATIC", RT_F_STATIC);
+    A.n_lanes = 0; A.f_inflight = tune_value("RT_F_INFLIGHT", RT_F_INFLIGHT); A.f_inflight_dense = tune_value("RT_F_INFLIGHT_DENSE", RT_F_INFLIGHT_DENSE); A.f_static = tune_value("RT_F_STATIC", RT_F_STATIC);
     const bool sched = mode == 0 && ns >= 4;
     // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame: call rt_render
     // (or rt_render_ctx_reserve) once before capturing it into a hipGraph.

@@ -140,6 +140,7 @@ struct RenderArgs {
     int32_t n_lanes;                      // lanes of the persistent render grid this launch will run on (64 x waves): the per-lane load is the yardstick of a "long" pixel
     const unsigned int* tail_list;        // the pixels of the last tiles of the hand-out order, most expensive 2x2 block first (k_tail_order); NULL = none
     float f_tail;                         // share of the launch's predicted work handed out per pixel instead of per tile, at the end of the queue
+    float f_inflight_dense;               // f_inflight of launches on dense grids (k_render<true,*,2>)
     float f_inflight, f_static;           // a pixel is long when its predicted chain exceeds f x (predicted iterations of the launch / n_lanes): found in flight / by the pilot
     const unsigned int* order;            // hand-out order of the local tiles (most expensive first), or NULL = identity
     const unsigned char* long_flag;       // per local pixel (local_tile*64 + l): pre-classified long chain, or NULL

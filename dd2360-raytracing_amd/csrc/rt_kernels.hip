@@ -1883,6 +1883,7 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     const int variant = render_variant(tree, 0, A.tree.acc);
     RenderArgs B = A;
     B.n_lanes = tree ? (int)render_grid_blocks(A, variant, 0) * 256 : 0;      // (list scans keep the rate rule alone)
+    if (variant == 2 && A.f_inflight_dense > 0.f) B.f_inflight = A.f_inflight_dense;
     { const hipError_t e = launch_pilot(A, tree, cost, pilot, nullptr, st); if (e != hipSuccess) return e; }
     // (chains in waves of their own: the variant for very sparse grids)
     return launch_select_and_order(B, cost, order, flags, long_list, st, 0, variant == 5 ? RT_PILOT_SOLO_SUM : 0x7fffffff);

@@ -30,8 +30,12 @@
 // 1.07 x load), so C3 does not move; an eighth of the C5 frame (load 2 250) needs them where the whole frame (18 000) does not.
 // Environment variables of the same names override the values per process (tuning sweeps on one build).  0 = off.
 #ifndef RT_F_INFLIGHT
-#define RT_F_INFLIGHT 1.35f
+#define RT_F_INFLIGHT 1.35f     // sparse grids (C3, load 663).  C3: 1.35: 16.56-16.69 ms, 1.1: 17.14-17.20, 0.9: 17.53-17.55; C2: 11.18 / 11.24 / 11.30
 #endif
+#ifndef RT_F_INFLIGHT_DENSE
+#define RT_F_INFLIGHT_DENSE 1.1f  // dense grids (k_render<true,*,2>).  An eighth of the C5 frame (load 2 250), slowest of the eight parts, two runs on one box:
+#endif                            // 1.35: 93.0 / 93.6 ms, 1.1: 90.9 / 92.3, 0.9: 92.8 / 93.4; the whole frame (load 18 000) does not see it
+
 #ifndef RT_F_STATIC
 #define RT_F_STATIC 1.07f
 #endif
