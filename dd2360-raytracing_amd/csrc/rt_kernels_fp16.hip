@@ -166,7 +166,11 @@ constexpr int kPP = RT_H16_PP;
 #ifdef RT_H16_STATS            // diagnostic build (tools/h16_phases.py): cycles per phase, summed over waves
 #define H16_TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_h16_cyc[8];
+#ifdef RT_H16_COUNTS           // (the counts build keeps slots 1 and 2 for closest_tree's rounds and calls)
+#define H16_ADD(k, t0) do { const unsigned long long now_ = H16_TICK(); if ((threadIdx.x & 63) == 0 && (k) != 1 && (k) != 2) atomicAdd(&g_h16_cyc[k], now_ - (t0)); (t0) = now_; } while (0)
+#else
 #define H16_ADD(k, t0) do { const unsigned long long now_ = H16_TICK(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_h16_cyc[k], now_ - (t0)); (t0) = now_; } while (0)
+#endif
 #ifdef RT_H16_COUNTS           // (per-lane atomics: distort every timing of the same run)
 #define H16_CNT(k, v) atomicAdd(&g_h16_cyc[k], (unsigned long long)(v))
 #define H16_FIRST_ACTIVE() ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true)))
@@ -452,7 +456,13 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     uint32_t ws_m = (live ? 0u : 1u) << 24, ws_n = 0u;          // wm0 | wm1 << 8 | wm2 << 16 | (lvl + 2) << 24;  wn1 | wn2 << 16
     const unsigned short* s_child16 = (const unsigned short*)(s_nodes + n_nodes);
     unsigned short* tp = L.u.tp + lane * kPlaneStride;
+#ifdef RT_H16_COUNTS
+    if (lane == 0) atomicAdd(&g_h16_cyc[2], 1ull);                   // (counts build: calls = wave-bounces)
+#endif
     while (true) {
+#ifdef RT_H16_COUNTS
+        if (lane == 0) atomicAdd(&g_h16_cyc[1], 1ull);               // (counts build: rounds)
+#endif
         if (lane == 0) { L.count = 0u; L.scount = 0u; }
         L.key[lane] = (unsigned long long)closest.bits << 32;
         if (np0 > 0) {

@@ -94,7 +94,8 @@ def test_c4_real_workload_fp16_against_the_oracle(rt, cuda):
 
 def test_c5_real_workload_8_part_split_against_the_oracle(rt, cuda):
     """BASELINE config 5: 3840x2160, 256 spp, NUM_SPHERES = 100000, octree SPL 320 (2.1 G samples), rendered the way the 8-GPU
-    job renders it — eight rt_partition parts (tile t -> part t % 8), compact tile-major buffers, rt_assemble — and as one whole
+    job renders it — eight rt_partition parts (runs of RT_PART_RUN = 64 consecutive tiles dealt round-robin: run r -> part r % 8, the
+    default split of rt_multi_render), compact tile-major buffers, rt_assemble — and as one whole
     frame: both equal bit for bit, and four rows of the frame and their RNG states equal the oracle."""
     torch = cuda
     nx, ny, ns, n, spl, nparts = 3840, 2160, 256, 100000, 320, 8

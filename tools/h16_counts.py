@@ -13,3 +13,4 @@ v = list(out)
 samples = nx * ny * ns
 print("per sample: candidates evaluated %.2f, past the float filter (exact roots) %.2f (%.1f %%)" % (v[5] / samples, v[6] / samples, 100.0 * v[6] / max(1, v[5])))
 if v[7]: print("walk loop: %.3g lane trips in %.3g wave trips -> %.1f of 64 lanes busy; %.1f lane trips per ray" % (v[4], v[7], v[4] / v[7], v[4] / (samples * 3.0)))
+print("closest_tree: %.3g calls of a wave, %.3g rounds -> %.2f rounds (plane tables, walks) per call" % (v[2], v[1], v[1] / max(1, v[2])))
