@@ -1152,9 +1152,6 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
     const unsigned int n_long_raw = A.long_list ? A.queue[2] : 0u, n_solo_raw = A.long_list ? A.queue[4] : 0u;
     const bool use_long = (n_long_raw + n_solo_raw) != 0u && (long long)(n_long_raw + n_solo_raw) * 64 <= n_slots;
     const unsigned int n_long = use_long ? n_long_raw : 0u, n_solo = use_long ? n_solo_raw : 0u;
-#ifdef RT_THR_HOIST
-    const unsigned int long_thr_k = MODE == 0 ? A.queue[kQueueThr] : 0u;
-#endif
     bool solo = false, solo_done = false;      // this wave started with one of the longest chains, alone (lane 0); that list is exhausted
     Rng s = {0, 0, 0, 0, 0, 0};
     V3 col = {0.0f, 0.0f, 0.0f};
@@ -1385,11 +1382,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                     // part of what ONE lane works through in this launch (queue[kQueueThr]; 0 when no scheduling pass ran)
                     bool now_long = false;
                     if ((sample & (RT_LONG_CHECK - 1)) == 0 && sample + 8 <= ns) {
-#ifdef RT_THR_HOIST
-                        const unsigned int long_thr = long_thr_k;
-#else
                         const unsigned int long_thr = MODE == 0 ? cold_args()->queue[kQueueThr] : 0u;
-#endif
                         now_long = iters >= (unsigned int)((COOPG == 2 ? RT_LONG_RATE_DENSE : RT_LONG_RATE) * sample) ||
                                    (long_thr != 0u && (unsigned long long)iters * (unsigned int)ns >= (unsigned long long)long_thr * (unsigned int)sample);
                     }
