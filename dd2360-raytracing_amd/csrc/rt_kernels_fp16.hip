@@ -163,6 +163,7 @@ constexpr int kSmall = RT_H16_SMALL;                          // small segments 
 constexpr unsigned kSmallPairs = 8u;                          // a node with fewer pairs is a small segment (its count must fit 3 bits)
 constexpr int kCand = 128;                                    // candidate queue of a wave
 constexpr int kPP = RT_H16_PP;
+constexpr int kTask = RT_H16_TASKS;                           // level-2 expansions a wave pools per round (regular trees)
 #ifdef RT_H16_STATS            // diagnostic build (tools/h16_phases.py): cycles per phase, summed over waves
 #define H16_TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 __device__ unsigned long long g_h16_cyc[8];
@@ -197,7 +198,10 @@ struct WaveLds {
             unsigned cq[kCand];          // candidates: entry index + 1 << 6 | owner
         } p2;
     } u;
-    unsigned count, scount, pad_[2];
+    // regular trees: the level-2 nodes that are still to be expanded, whoever's ray they belong to — node | owner lane << 10 |
+    // leaf children still to be pooled << 16 | expanded << 24 (closest_tree, phase 1b)
+    unsigned task[kTask];
+    unsigned count, scount, tcount, tbegin;                  // (tbegin: first task of the pool that is not done)
 };
 static_assert(sizeof(WaveLds) % 16 == 0, "WaveLds keeps 16-byte alignment");
 
@@ -450,10 +454,9 @@ RT_DEV void closest_tree(const DevScene& S, const DevTree& T, const float4* s_no
     const int n_nodes = T.n_nodes;
     const int np0 = T.h16_np[0], np1 = T.h16_np[1], np2 = T.h16_np[2];
     const bool regular = regular_planes(T);
-    // the walk of a regular tree (below): which level the lane is expanding (-1: done, -2: not started), the level-1 and level-2
-    // nodes it is inside, and per level the children that passed and are still to be visited
-    // (between the walks of two rounds the six values live packed in two registers: the test loop needs every register it can get)
-    uint32_t ws_m = (live ? 0u : 1u) << 24, ws_n = 0u;          // wm0 | wm1 << 8 | wm2 << 16 | (lvl + 2) << 24;  wn1 | wn2 << 16
+    // (between the walks of two rounds a lane's state is ONE register, the wave's lives in LDS: the test loop needs every register it can get)
+    uint32_t ws_m = (live ? 0u : 1u) << 26;                     // level-1 children to expand | children waiting for the task pool << 8 | their level-1 node << 16 | started << 26
+    if (lane == 0) { L.tcount = 0u; L.tbegin = 0u; }
     const unsigned short* s_child16 = (const unsigned short*)(s_nodes + n_nodes);
     unsigned short* tp = L.u.tp + lane * kPlaneStride;
 #ifdef RT_H16_COUNTS
@@ -482,52 +485,84 @@ _Pragma("unroll 1") for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = rf(div_by(
         //      pool is full).  traverseTree (acceleration_structure.h:276-304) visits a node's non-zero children in index order,
         //      each after its own slab test; which nodes are visited does not depend on the order, and neither does the result (above).
         if (regular) {
-            int lvl = (int)(ws_m >> 24) - 2, wn1 = (int)(ws_n & 0xffffu), wn2 = (int)(ws_n >> 16);
-            unsigned wm0 = ws_m & 255u, wm1 = (ws_m >> 8) & 255u, wm2 = (ws_m >> 16) & 255u;
-            // A step of the lane is either the expansion of an inner node — its eight children's slab tests at once — or the visit
-            // of a level-3 child that passed: ~11 steps a ray instead of one dependent LDS chain per tested node (27 a ray).
-            if (lvl == -2) {
-                lvl = -1;
+            // Phase 1a, every lane for its own ray: the root's slab test and expansion, then the expansion of every level-1 child that
+            // passed — each yields the level-2 children that pass, which are NOT expanded here: they go into the wave's task pool.
+            // Phase 1b: the pooled level-2 expansions are dealt out evenly, 64 a pass, whoever's ray they belong to (the owner's plane
+            // table is in LDS); the leaves that pass become segments.  A ray through the sphere field needs four or five expansions,
+            // a ray into the sky one: walked lane by lane (rounds 2-3) the loop ran 13 trips a call at 27 of 64 lanes busy.
+            // Which nodes are visited does not depend on who expands them or when, and neither does the result (above).
+            unsigned wm0 = ws_m & 255u, pmask = (ws_m >> 8) & 255u; bool started = ((ws_m >> 26) & 1u) != 0u;
+            int pnode = (int)((ws_m >> 16) & 1023u);                 // (a level-1 node's passing children that found the task pool full)
+            if (!started) {
+                started = true;
                 const uint32_t w0 = (uint32_t)__float_as_int(s_nodes[0].w);
-                if (ray_box_tab(tp, w0)) {
-                    if (((w0 >> 5) & 31u) - (w0 & 31u) > 1u) { wm0 = expand_node(tp, w0) & (unsigned)__float_as_int(s_nodes[0].y); lvl = 0; }
-                }
+                if (ray_box_tab(tp, w0) && ((w0 >> 5) & 31u) - (w0 & 31u) > 1u) wm0 = expand_node(tp, w0) & (unsigned)__float_as_int(s_nodes[0].y);
             }
-            // (wm2: level-3 children of the level-2 node wn2 that passed and are still to be pooled — visited right after the
-            // expansion that found them, left over only when a pool was full)
-            auto pool_leaves = [&]() -> bool {                          // false: a pool is full, the rest waits for the next round
-                while (wm2 != 0u) {
-                    const int c = __builtin_ctz(wm2);
-                    const float4 nd = s_nodes[(int)s_child16[wn2 * 8 + c]];         // (skip, first pair, pairs, plane indices)
-                    const uint32_t first = (uint32_t)__float_as_int(nd.y); const unsigned cnt = (unsigned)__float_as_int(nd.z);
-                    if (cnt >= kSmallPairs) {
-                        const unsigned slot = atomicAdd(&L.count, 1u);
-                        if (slot >= (unsigned)kBig) return false;
-                        L.seg[slot] = make_uint2(first | ((uint32_t)lane << 26), cnt);
-                    } else if (cnt > 0u) {
-                        const unsigned slot = atomicAdd(&L.scount, 1u);
-                        if (slot >= (unsigned)kSmall) return false;
-                        L.sseg[slot] = first | (cnt << 23) | ((uint32_t)lane << 26);
-                    }
-                    wm2 &= wm2 - 1u;
+            bool room = true;
+            auto push_tasks = [&]() {                               // pmask's level-2 children of pnode -> tasks; false: the pool is full
+                const unsigned n = (unsigned)__popc(pmask);
+                const unsigned slot = atomicAdd(&L.tcount, n);
+                if (slot + n > (unsigned)kTask) { atomicSub(&L.tcount, n); return false; }
+                unsigned k = slot;
+                while (pmask != 0u) {
+                    const int c = __builtin_ctz(pmask); pmask &= pmask - 1u;
+                    L.task[k++] = (unsigned)s_child16[pnode * 8 + c] | ((unsigned)lane << 10) | (0xffu << 16);
                 }
                 return true;
             };
-            bool room = pool_leaves();                                  // (left over from the previous round)
-            while (room && lvl >= 0) {                                  // lvl 0: inside the root, 1: inside the level-1 node wn1
-                const unsigned m = lvl == 0 ? wm0 : wm1;
+            if (pmask != 0u) room = push_tasks();
+            while (room && wm0 != 0u) {
                 H16_CNT(4, 1); if (H16_FIRST_ACTIVE()) H16_CNT(7, 1);       // (counts build: lane trips / wave trips of this loop)
-                if (m == 0u) { --lvl; continue; }
-                const int c = __builtin_ctz(m);
-                const int child = (int)s_child16[(lvl == 0 ? 0 : wn1) * 8 + c];
-                if (lvl == 0) wm0 = m & (m - 1u); else wm1 = m & (m - 1u);
-                const float4 nd = s_nodes[child];                      // (skip, existing children, -, plane indices)
-                const unsigned cm = expand_node(tp, (uint32_t)__float_as_int(nd.w)) & (unsigned)__float_as_int(nd.y);      // ... of the children that exist
-                if (lvl == 0) { wn1 = child; wm1 = cm; lvl = 1; }
-                else { wn2 = child; wm2 = cm; room = pool_leaves(); }
+                const int c = __builtin_ctz(wm0); wm0 &= wm0 - 1u;
+                pnode = (int)s_child16[c];                              // (the root's child by octant)
+                const float4 nd = s_nodes[pnode];                       // (skip, existing children, -, plane indices)
+                pmask = expand_node(tp, (uint32_t)__float_as_int(nd.w)) & (unsigned)__float_as_int(nd.y);
+                if (pmask != 0u) room = push_tasks();
             }
-            if (lvl < 0 && wm2 == 0u) node = n_nodes;
-            ws_m = wm0 | (wm1 << 8) | (wm2 << 16) | ((uint32_t)(lvl + 2) << 24); ws_n = (uint32_t)wn1 | ((uint32_t)wn2 << 16);
+            ws_m = wm0 | (pmask << 8) | ((uint32_t)pnode << 16) | ((started ? 1u : 0u) << 26);
+            wave_sync();
+            // ---- phase 1b
+            const unsigned n_task = __builtin_amdgcn_readfirstlane(L.tcount);
+            unsigned t_begin = __builtin_amdgcn_readfirstlane(L.tbegin);
+            bool stuck = false;
+            while (t_begin < n_task) {
+                const unsigned ti = t_begin + (unsigned)lane;
+                unsigned e = ti < n_task ? L.task[ti] : (1u << 24);  // (no task: expanded, nothing left)
+                const int tnode = (int)(e & 1023u), towner = (int)((e >> 10) & 63u);
+                if (!((e >> 24) & 1u)) {
+                    H16_CNT(4, 1);
+                    const float4 nd = s_nodes[tnode];
+                    const unsigned cm = expand_node(L.u.tp + towner * kPlaneStride, (uint32_t)__float_as_int(nd.w)) & (unsigned)__float_as_int(nd.y);
+                    e = (e & 0xffffu) | (cm << 16) | (1u << 24);
+                }
+                if (H16_FIRST_ACTIVE()) H16_CNT(7, 1);
+                unsigned lm = (e >> 16) & 255u;
+                while (lm != 0u) {
+                    const int c = __builtin_ctz(lm);
+                    const float4 nd = s_nodes[(int)s_child16[tnode * 8 + c]];         // (skip, first pair, pairs, plane indices)
+                    const uint32_t first = (uint32_t)__float_as_int(nd.y); const unsigned cnt = (unsigned)__float_as_int(nd.z);
+                    if (cnt >= kSmallPairs) {
+                        const unsigned slot = atomicAdd(&L.count, 1u);
+                        if (slot >= (unsigned)kBig) break;
+                        L.seg[slot] = make_uint2(first | ((uint32_t)towner << 26), cnt);
+                    } else if (cnt > 0u) {
+                        const unsigned slot = atomicAdd(&L.scount, 1u);
+                        if (slot >= (unsigned)kSmall) break;
+                        L.sseg[slot] = first | (cnt << 23) | ((uint32_t)towner << 26);
+                    }
+                    lm &= lm - 1u;
+                }
+                if (ti < n_task) L.task[ti] = (e & 0xff00ffffu) | (lm << 16);
+                if (__ballot(lm != 0u) != 0ull) { stuck = true; break; }        // a segment pool is full: this pass again after the tests
+                t_begin += 64u;
+            }
+            wave_sync();
+            // all done: no lane has children left to expand and no task waits; then the pool starts over
+            const bool lane_open = wm0 != 0u || pmask != 0u;
+            const bool more = stuck || t_begin < n_task || __ballot(lane_open) != 0ull;
+            if (!more) node = n_nodes;
+            if (!stuck && t_begin >= n_task) { t_begin = 0u; if (lane == 0) L.tcount = 0u; }     // (every task done: a fresh pool for the lanes that still hold children)
+            if (lane == 0) L.tbegin = t_begin;
         } else
         while (node < n_nodes) {
             bool pass; int skip; uint32_t first; unsigned cnt;
@@ -559,7 +594,12 @@ _Pragma("unroll 1") for (int k = 0; k < np2; ++k) tp[np0 + np1 + k] = rf(div_by(
         H16_ADD(0, tph);                                             // walk
         const unsigned n_seg = min(__builtin_amdgcn_readfirstlane(L.count), (unsigned)kBig);
         const unsigned n_small = min(__builtin_amdgcn_readfirstlane(L.scount), (unsigned)kSmall);
-        if (n_seg == 0u && n_small == 0u) break;                     // (then no lane is stalled either)
+        if (n_seg == 0u && n_small == 0u) {
+            // nothing to test this round.  Lanes stalled by a full SEGMENT pool cannot exist then; lanes whose level-2 nodes found
+            // the TASK pool full can (regular trees): they go on next round
+            if (__ballot(node < n_nodes) == 0ull) break;
+            continue;
+        }
         // this lane's ray for whoever tests its spheres (the plane table's space: the walk is over)
         L.u.p2.ray[2 * lane] = make_uint4(dup16(r.o.x), dup16(r.o.y), dup16(r.o.z), dup16(r.d.x));
         L.u.p2.ray[2 * lane + 1] = make_uint4(dup16(r.d.y), dup16(r.d.z), dup16(a), 0u);

@@ -137,6 +137,9 @@
 #ifndef RT_H16_SMALL
 #define RT_H16_SMALL 256        // small segments per round (C4: the 56 upper cells that hold one large sphere each)
 #endif
+#ifndef RT_H16_TASKS
+#define RT_H16_TASKS 384        // level-2 node expansions a wave pools per round of the binary16 walk (1.5 KB of LDS; four waves per SIMD leave room for ~450)
+#endif
 #ifndef RT_H16_PP
 #define RT_H16_PP 10            // pairs per lane and pass of the big segments' test loop (at most 16: pass_mask).  C4, round 3: 4: 38.3 ms, 6: 37.9, 8: 37.05; with the ray out of the registers during the tests (closest_tree, phase 3): 8: 35.6, 10: 35.1, 12: 35.4
 #endif
