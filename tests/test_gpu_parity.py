@@ -377,6 +377,38 @@ def test_fp16_trace_hit_records(rt, cuda, tree):
     assert np.array_equal(bits(got["normal"]), bits(ref["normal"]))
 
 
+def test_fp16_rays_that_pass_every_node_of_the_tree(rt, cuda):
+    """The binary16 walk pools the level-2 node expansions of a wave's rays (rt_kernels_fp16.hip, closest_tree): a task pool of 384
+    entries, segment pools of 128 / 256.  Rays from (-49152, -49152, -49152): in binary16 every box plane of the tree lies at the same
+    rounded distance from such an origin (spacing 32 up there), every slab interval degenerates to one point, and with equal direction
+    components all three coincide — EVERY node passes intersect_ray_aabb (acceleration_structure.h:226-244: closed comparisons), every
+    leaf is visited, whole waves of such rays overflow the task pool and the segment pools many times over.  The records (and those of
+    ordinary rays in the same launch, and of rays degenerate on one or two axes only) equal the oracle's hitTree, bit for bit."""
+    torch = cuda
+    n, spl = 10000, 32
+    rng = np.random.default_rng(5)
+    far = np.float32(-49152.0)
+    blocks = []
+    a = np.tile(np.array([far, far, far, 1, 1, 1], np.float32), (512, 1)); blocks.append(a)                      # every node passes
+    b = random_rays(2048, 11); b[:, 0] = far; b[:, 3] = np.abs(b[:, 3]) + 0.5; blocks.append(b)                  # degenerate on x only
+    c = random_rays(2048, 12); c[:, 0] = far; c[:, 2] = far; c[:, 3] = 1.0; c[:, 5] = 1.0; blocks.append(c)       # on x and z, equal parameters
+    d = np.tile(np.array([far, far, far, 1, 1, 1], np.float32), (256, 1)); d[:, 3:] *= rng.choice([0.5, 1.0, 2.0], (256, 3)).astype(np.float32); blocks.append(d)
+    blocks.append(random_rays(20000, 13))
+    rays = np.ascontiguousarray(np.concatenate(blocks), np.float32).astype(np.float16).astype(np.float32)
+    nrays = rays.shape[0]
+    W = rt.World(n, 1200, 800, precision=rt.FP16)
+    O = rt.Octree(W, spl)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_out = torch.zeros(nrays * 32, dtype=torch.uint8, device="cuda")
+    rt.trace_rays(W, O, d_rays, nrays, d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(rt.hit_record_dtype)
+    ref = OracleScene(n, 1200, 800, fp16=True, use_octree=True, spl=spl).trace(rays, mode=2)
+    assert np.array_equal(got["sphere"], ref["sphere"])
+    assert np.array_equal(bits(got["t"]), bits(ref["t"])) and np.array_equal(bits(got["normal"]), bits(ref["normal"]))
+    assert ref["hit"][512 + 4352:].sum() > 1000                         # the ordinary rays of the launch do hit
+
+
 def test_fp16_progressive_and_partition(rt, cuda):
     torch = cuda
     nx, ny, n = 56, 40, 500
