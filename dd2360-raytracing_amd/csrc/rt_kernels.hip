@@ -1196,10 +1196,11 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
                 const unsigned int pid = A.tail_list[slot - (tail0 - 1)];
                 local_tile = (long long)(pid >> 6); l = (int)(pid & 63u);
             } else {
-                const long long blk = slot >> 12;
-                const long long tiles_in_blk = (A.n_local_tiles - blk * 64) < 64 ? (A.n_local_tiles - blk * 64) : 64;
-                const long long within = slot & 4095;
-                const long long rank = blk * 64 + within % tiles_in_blk;          // position in the hand-out order
+                constexpr int kIl = COOPG == 2 ? RT_INTERLEAVE_DENSE : (COOPG == 5 ? RT_INTERLEAVE_SOLO : RT_INTERLEAVE);   // tiles whose pixels interleave (consecutive slots: one pixel position of kIl tiles)
+                const long long blk = slot / (64 * kIl);
+                const long long tiles_in_blk = (A.n_local_tiles - blk * kIl) < kIl ? (A.n_local_tiles - blk * kIl) : kIl;
+                const long long within = slot % (64 * kIl);
+                const long long rank = blk * kIl + within % tiles_in_blk;          // position in the hand-out order
                 l = (int)(within / tiles_in_blk);
                 local_tile = A.order ? (long long)A.order[rank] : rank;
             }

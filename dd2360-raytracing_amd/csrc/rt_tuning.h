@@ -42,6 +42,18 @@
 #ifndef RT_F_TAIL
 #define RT_F_TAIL 0.15f         // share of a launch's predicted work whose pixels are handed out one by one, most expensive 2x2 pilot block first, at the end of the
 #endif                          // queue (k_tail_order) instead of tile by tile; 0 = off
+// Consecutive pixel slots are the same pixel position of RT_INTERLEAVE different tiles (in hand-out order): long pixels cluster, and a tile's
+// pixels should not travel together — but rays of neighbouring pixels meet the same spheres, and a wave whose lanes hold 64 different tiles
+// finds nothing in its cache.  64: a tile's 64 pixels start in 64 waves; 16: in sixteen, four pixels of the tile each.
+#ifndef RT_INTERLEAVE
+#define RT_INTERLEAVE 64        // sparse grids (C3: chain-bound).  C3, two runs: 64: 16.79 / 16.63 ms, 32: 16.58 / 16.62, 16: 16.48 / 16.59, 8: 16.75 / 16.69, 4: 16.47 / 16.68, 1: 17.01 / 17.20
+#endif
+#ifndef RT_INTERLEAVE_DENSE
+#define RT_INTERLEAVE_DENSE 16  // dense grids (C5).  The eight parts of the frame, slowest / sum (ms), two runs each: 64: 92.4 / 722, 91.9 / 723; 32: 92.0 / 718, 91.0 / 714;
+#endif                          // 16: 90.0 / 708, 90.6 / 709; 8: 89.8 / 700, 90.4 / 705; 4: 94.8 / 721; 1: 108.7 / 772.  Whole frame: 638.5 -> 637.0 (16), 636.3 (8)
+#ifndef RT_INTERLEAVE_SOLO
+#define RT_INTERLEAVE_SOLO 1    // very sparse grids with solo chains (C2: k_render<true,*,5>).  C2: 64: 11.09 ms, 16: 11.00, 4: 10.96, 1: 10.69
+#endif
 #ifndef RT_LONG_RATE_MIN
 #define RT_LONG_RATE_MIN 8      // ... but never below this many bounces per sample / this 3x3 pilot sum (launches of a pixel or two per lane)
 #endif
