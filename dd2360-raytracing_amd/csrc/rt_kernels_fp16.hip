@@ -843,10 +843,11 @@ __global__ __launch_bounds__(256, RT_H16_MINWAVES) void k_render_h(RenderArgs A)
         live = false; is_long = false;
         while (slot < n_slots) {
             // consecutive slots are the same pixel position of 64 different tiles (in hand-out order): the pixels of a tile never travel together
-            const long long blk = slot >> 12;
-            const long long tiles_in_blk = (A.n_local_tiles - blk * 64) < 64 ? (A.n_local_tiles - blk * 64) : 64;
-            const long long within = slot & 4095;
-            const long long rank = blk * 64 + within % tiles_in_blk;
+            constexpr int kIl = RT_H16_INTERLEAVE;                   // (rt_tuning.h: tiles whose pixels interleave)
+            const long long blk = slot / (64 * kIl);
+            const long long tiles_in_blk = (A.n_local_tiles - blk * kIl) < kIl ? (A.n_local_tiles - blk * kIl) : kIl;
+            const long long within = slot % (64 * kIl);
+            const long long rank = blk * kIl + within % tiles_in_blk;
             const int l = (int)(within / tiles_in_blk);
             const long long local_tile = A.order ? (long long)A.order[rank] : rank;
             const long long tile = part_tile(local_tile, A.part, A.nparts, A.tile_begin, A.tile_end);

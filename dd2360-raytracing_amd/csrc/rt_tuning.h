@@ -149,6 +149,9 @@
 #ifndef RT_H16_SMALL
 #define RT_H16_SMALL 256        // small segments per round (C4: the 56 upper cells that hold one large sphere each)
 #endif
+#ifndef RT_H16_INTERLEAVE
+#define RT_H16_INTERLEAVE 64    // tiles over which consecutive pixel slots interleave (as RT_INTERLEAVE).  C4: 64: 30.8 / 30.9 ms, 16: 31.9 / 32.2, 4: 35.7 / 34.9, 1: 39.3 / 38.4
+#endif
 #ifndef RT_H16_TASKS
 #define RT_H16_TASKS 384        // level-2 node expansions a wave pools per round of the binary16 walk (1.5 KB of LDS; four waves per SIMD leave room for ~450)
 #endif
