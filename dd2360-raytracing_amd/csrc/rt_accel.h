@@ -35,9 +35,9 @@ template <class T> using RawVec = std::vector<T, NoInit<T>>;
 
 struct AccelHost {
     std::vector<float4> large_hot; std::vector<int32_t> large_id;
-    std::vector<int32_t> cs; RawVec<float4> hot;                      // x-major copy followed by z-major copy, then 16 pad entries
+    std::vector<int32_t> cs; RawVec<float4> hot;                      // x copy followed by z copy, then 16 pad entries
     RawVec<float4> brick; std::vector<float4> large_brick;            // per entry: two float4 (DevAccel::brick)
-    size_t n_entries = 0;                                             // registrations per copy
+    size_t n_entries = 0, n_entries_z = 0;                            // registrations of the x copy (columns along x) and of the z copy
     std::vector<int32_t> memb_start, memb_cell;
     std::vector<int32_t> cellnode;                            // 8x8x8 level-3 cells of the root box -> pre-order node
     std::vector<int32_t> bits_index; std::vector<uint32_t> cellbits;   // membership bitmaps of the spheres stored in several nodes
@@ -56,6 +56,9 @@ constexpr double kSlack = 2e-3;         // rasterisation slack (absorbs float er
 // rounded up.  (0.012 cost 2.7 % of the C3 frame: the lowest 3 % of a sphere resting on y = 0 fell outside its brick.)
 constexpr double kBrickMxz = 0.0008, kBrickMy = 0.0085;
 // 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
+#ifndef RT_ACCEL_FINE
+#define RT_ACCEL_FINE 4          // fine bins per cell along a column (a power of two)
+#endif
 #ifndef RT_DENSE_CELL
 #define RT_DENSE_CELL 0.7
 #endif
@@ -63,6 +66,16 @@ constexpr double kDenseCell = RT_DENSE_CELL;     // cell size of dense scenes, i
 __host__ __device__ inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
 // inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
 __host__ __device__ inline double accel_Rp(double r2) { return sqrt(r2 * (1.0 + 1e-6) + accel_K2()) + 1e-5 + kSlack; }
+// fine bin of a sphere's centre coordinate c along a column (bin width h / F, Gf = G * F bins from g0 on).  One expression for the host
+// build and the device build (rt_build.hip): the two must agree bin for bin.
+__host__ __device__ inline int accel_fine_bin(double c, double g0, double h, int F, int Gf) {
+    const int b = (int)floor((c - g0) / h * (double)F);
+    return b < 0 ? 0 : (b > Gf - 1 ? Gf - 1 : b);
+}
+// What the walk grows a column query by, in cell units: a sphere can matter where the line passes within its inflated radius R' of
+// the centre (R' <= rmax: accel_Rp, which carries the rasterisation slack of the registration); the walk's own float error (~1e-5
+// cells) is covered by kSlack once more, as in the cell-range form of rounds 1-3.
+inline float accel_query_growth(double rmax, double h) { return (float)(((rmax + 1e-4 + kSlack) / h) * (1.0 + 1e-6)); }
 
 // nodes/ent_id: the pre-order traversal copy; geom_r2(i) gives (cx,cy,cz,r^2) of world-list index i
 // list_mode: `nodes` is the single unbounded node that stands for hitable_list::hit (every sphere is eligible everywhere:
@@ -171,10 +184,13 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     const int G = (int)std::ceil(2.0 * half / h);
     const double g0 = -half;
     p.G = G; p.g0 = (float)g0; p.h = (float)h; p.inv_h = (float)(1.0 / h);
-    // 3. classify + register
-    struct Reg { int s, ix0, ix1, iz0, iz1; };
+    // 3. classify + register.  A grid sphere goes ONCE into every column its inflated extent overlaps, keyed by the fine bin of its
+    // CENTRE along the column (accel_fine_bin): the walk grows its query by the largest inflated radius instead (DevAccel::rq_c).
+    const int F = RT_ACCEL_FINE, Gf = G * F;
+    p.F = F; p.Gf = Gf;
+    struct Reg { int s, ix0, ix1, iz0, iz1, bx, bz; };
     std::vector<Reg> regs;
-    double ylo = 1e30, yhi = -1e30, rmax = 0;
+    double ylo = 1e30, yhi = -1e30, rmax = 0, cells = 0;
     for (int s = 0; s < n_world; ++s) {
         if (!in_tree[s]) continue;
         const float4 g = hot_of[s];
@@ -189,53 +205,57 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         r.ix0 = (int)std::floor((g.x - Rp - g0) / h - 1e-4); r.ix1 = (int)std::floor((g.x + Rp - g0) / h + 1e-4);
         r.iz0 = (int)std::floor((g.z - Rp - g0) / h - 1e-4); r.iz1 = (int)std::floor((g.z + Rp - g0) / h + 1e-4);
         r.ix0 = std::max(0, r.ix0); r.iz0 = std::max(0, r.iz0); r.ix1 = std::min(G - 1, r.ix1); r.iz1 = std::min(G - 1, r.iz1);
+        r.bx = accel_fine_bin((double)g.x, g0, h, F, Gf); r.bz = accel_fine_bin((double)g.z, g0, h, F, Gf);
         regs.push_back(r);
+        cells += (double)(r.ix1 - r.ix0 + 1) * (double)(r.iz1 - r.iz0 + 1);
         ylo = std::min(ylo, (double)g.y - Rp); yhi = std::max(yhi, (double)g.y + Rp); rmax = std::max(rmax, Rp);
     }
     p.n_large = (int)A.large_id.size();
-    const size_t ncell = (size_t)G * G;
-    std::vector<int32_t> cs_x(ncell + 1, 0), cs_z(ncell + 1, 0);
-    for (const Reg& r : regs)
-        for (int ix = r.ix0; ix <= r.ix1; ++ix)
-            for (int iz = r.iz0; iz <= r.iz1; ++iz) { cs_x[(size_t)ix * G + iz + 1]++; cs_z[(size_t)iz * G + ix + 1]++; }
-    for (size_t c = 0; c < ncell; ++c) { cs_x[c + 1] += cs_x[c]; cs_z[c + 1] += cs_z[c]; }
-    const size_t total = (size_t)cs_x[ncell];
-    A.n_entries = total;
+    const size_t ncell = (size_t)G * G, nbin = (size_t)G * Gf;
+    std::vector<int32_t> cs_x(nbin + 1, 0), cs_z(nbin + 1, 0);
+    for (const Reg& r : regs) {
+        for (int ix = r.ix0; ix <= r.ix1; ++ix) cs_x[(size_t)ix * Gf + r.bz + 1]++;
+        for (int iz = r.iz0; iz <= r.iz1; ++iz) cs_z[(size_t)iz * Gf + r.bx + 1]++;
+    }
+    for (size_t c = 0; c < nbin; ++c) { cs_x[c + 1] += cs_x[c]; cs_z[c + 1] += cs_z[c]; }
+    const size_t nx = (size_t)cs_x[nbin], nz = (size_t)cs_z[nbin], total = nx + nz;
+    A.n_entries = nx; A.n_entries_z = nz;
     // the kernel reads entries in batches and may over-read past a range: 16 pad entries that can never test positive
-    A.hot.resize(2 * total + 16);
-    A.brick.resize(4 * total + 32);
-    // fill in sphere order (a counting sort by cell, once x-major and once z-major).  The time goes into first-touch page
-    // faults and cache misses of the scattered writes, not into arithmetic: worker threads over bands of rows, huge pages
-    // and pre-populated mappings were tried at N = 100 000 (57 MB) and gained nothing over this loop.
+    A.hot.resize(total + 16);
+    A.brick.resize(2 * total + 32);
+    // fill in sphere order (a counting sort by bin, once with columns along x and once along z): within a bin, ascending sphere index
     {
         std::vector<int32_t> fx(cs_x.begin(), cs_x.end() - 1), fz(cs_z.begin(), cs_z.end() - 1);
         for (const Reg& r : regs) {
             const float4 g = hot_of[r.s], blo = sb_lo[r.s], bhi = sb_hi[r.s];
-            for (int ix = r.ix0; ix <= r.ix1; ++ix)
-                for (int iz = r.iz0; iz <= r.iz1; ++iz) {
-                    const size_t a = (size_t)fx[(size_t)ix * G + iz]++, b = total + (size_t)fz[(size_t)iz * G + ix]++;
-                    A.hot[a] = g; A.brick[2 * a] = blo; A.brick[2 * a + 1] = bhi;
-                    A.hot[b] = g; A.brick[2 * b] = blo; A.brick[2 * b + 1] = bhi;
-                }
+            for (int ix = r.ix0; ix <= r.ix1; ++ix) {
+                const size_t a = (size_t)fx[(size_t)ix * Gf + r.bz]++;
+                A.hot[a] = g; A.brick[2 * a] = blo; A.brick[2 * a + 1] = bhi;
+            }
+            for (int iz = r.iz0; iz <= r.iz1; ++iz) {
+                const size_t b = nx + (size_t)fz[(size_t)iz * Gf + r.bx]++;
+                A.hot[b] = g; A.brick[2 * b] = blo; A.brick[2 * b + 1] = bhi;
+            }
         }
     }
     { const float qn = std::nanf("");
-      for (size_t k = 2 * total; k < 2 * total + 16; ++k) { A.hot[k] = make_float4(qn, qn, qn, qn); A.brick[2 * k] = make_float4(qn, qn, qn, 0.f); A.brick[2 * k + 1] = make_float4(qn, qn, qn, qn); } }
+      for (size_t k = total; k < total + 16; ++k) { A.hot[k] = make_float4(qn, qn, qn, qn); A.brick[2 * k] = make_float4(qn, qn, qn, 0.f); A.brick[2 * k + 1] = make_float4(qn, qn, qn, qn); } }
     if (A.large_brick.empty()) A.large_brick.assign(2, make_float4(0, 0, 0, 0));
-    A.cs.resize(2 * (ncell + 1));
-    for (size_t c = 0; c <= ncell; ++c) { A.cs[c] = cs_x[c]; A.cs[ncell + 1 + c] = (int32_t)total + cs_z[c]; }
-    p.zoff = (int32_t)(ncell + 1);
+    A.cs.resize(2 * (nbin + 1));
+    for (size_t c = 0; c <= nbin; ++c) { A.cs[c] = cs_x[c]; A.cs[nbin + 1 + c] = (int32_t)nx + cs_z[c]; }
+    p.zoff = (int32_t)(nbin + 1);
     if (regs.empty()) { ylo = 0; yhi = 0; }
     p.ylo = (float)(ylo - 1e-4); p.yhi = (float)(yhi + 1e-4); p.rmax = (float)(rmax + 1e-4);
+    p.rq_c = accel_query_growth(rmax, h);
     p.zone2 = (float)(kZone * kZone);
     p.enabled = 1;
     // rays side by side in the cooperative walk pay off while a chunk of 8 columns is a handful of entries (C3: 3.6 per cell);
     // on dense grids (C5: N = 100 000, ~40 per cell) an uneven pair of rays costs twice the longer one
-    p.coop_groups = (double)total <= 8.0 * (double)ncell ? 4 : 1;
+    p.coop_groups = cells <= 8.0 * (double)ncell ? 4 : 1;
     // very sparse grids (lists of a few hundred spheres): the frame waits for its pixel chains with the chip half idle, so every
     // pre-classified chain starts ALONE in a wave (C2: 13.4 -> 11.6 ms); at C3's 3.6 entries per cell the waves set aside cost
     // more throughput than the chains gain (profiles/r3/chain_cache_ab.txt)
-    p.solo_chains = (double)total <= RT_SOLO_DENSITY * (double)ncell ? 1 : 0;
+    p.solo_chains = cells <= RT_SOLO_DENSITY * (double)ncell ? 1 : 0;
 }
 
 } // namespace rt

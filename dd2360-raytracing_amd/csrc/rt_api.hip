@@ -612,7 +612,7 @@ int rt_octree_debug_array(const rt_octree* O, int which, void* out, size_t cap, 
         return (int)hipMemcpy(out, src16, sz16, hipMemcpyDeviceToHost);
     }
     const DevAccel& p = Z.dev.acc;
-    const size_t total = O->accel.n_entries, ncell = (size_t)O->accel.p.G * O->accel.p.G, nl = (size_t)O->accel.p.n_large;
+    const size_t total = O->accel.n_entries + O->accel.n_entries_z, nbin = (size_t)O->accel.p.G * O->accel.p.Gf, nl = (size_t)O->accel.p.n_large;
     const void* src = nullptr; size_t sz = 0;
     switch (which) {
         case 0: src = Z.dev.nodes4; sz = (size_t)O->n_nodes * sizeof(DevNode); break;
@@ -620,9 +620,9 @@ int rt_octree_debug_array(const rt_octree* O, int which, void* out, size_t cap, 
         case 2: src = Z.dev.ent_id; sz = (size_t)O->n_entries * 4; break;
         case 3: src = p.large_hot; sz = nl * 16; break;
         case 4: src = p.large_brick; sz = (nl ? nl : 1) * 32; break;
-        case 5: src = p.cs; sz = O->accel.p.enabled || total ? 2 * (ncell + 1) * 4 : 0; break;
-        case 6: src = p.hot; sz = O->accel.p.G ? (2 * total + 16) * 16 : 0; break;
-        case 7: src = p.brick; sz = O->accel.p.G ? (2 * total + 16) * 32 : 0; break;
+        case 5: src = p.cs; sz = O->accel.p.enabled || total ? 2 * (nbin + 1) * 4 : 0; break;
+        case 6: src = p.hot; sz = O->accel.p.G ? (total + 16) * 16 : 0; break;
+        case 7: src = p.brick; sz = O->accel.p.G ? (total + 16) * 32 : 0; break;
         case 8: src = p.memb_start; sz = ((size_t)O->n_world + 1) * 4; break;
         case 9: src = p.memb_cell; sz = (size_t)O->n_entries * 4; break;
         case 10: src = p.cellnode; sz = 512 * 4; break;

@@ -39,6 +39,7 @@ struct Counters {
     unsigned node_count, leaf_count, n_entries, in_tree;
     unsigned median_bits, bit_rows, n_large, reg_total;
     unsigned long long ylo, yhi, rmax;       // order-preserving encodings of doubles (min, max, max)
+    unsigned long long reg_cells;            // cells the grid spheres' inflated squares overlap, summed (build_accel's density measure)
 };
 
 // a double as an unsigned integer with the same order
@@ -333,15 +334,17 @@ __global__ __launch_bounds__(256) void k_bitrows(int n_world, const int32_t* __r
     for (int q = 0; q < 16; ++q) cellbits[(size_t)row * 16 + q] = w[q];
 }
 
-struct GridParams { double g0, h, Rlim; int G; };
+struct GridParams { double g0, h, Rlim; int G, F, Gf; };
 
-// large list or grid registration of every tree sphere (rt_accel.h step 3)
+// large list or grid registration of every tree sphere (rt_accel.h step 3): the columns its inflated extent overlaps along x and
+// along z, and the fine bins of its centre
 __global__ __launch_bounds__(256) void k_classify(int n_world, const int32_t* __restrict__ memb_start, const float4* __restrict__ hot_of, GridParams P,
-                                                  int* is_large, int* nreg, int4* range, Counters* C) {
+                                                  int* is_large, int* nreg_x, int* nreg_z, int4* range, int2* bins, Counters* C) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_world) return;
-    int large = 0, cnt = 0;
+    int large = 0, cx = 0, cz = 0;
     int4 r = make_int4(0, 0, 0, 0);
+    int2 bn = make_int2(0, 0);
     if (memb_start[s + 1] > memb_start[s]) {
         const float4 g = hot_of[s];
         const double Rp = accel_Rp((double)g.w);
@@ -353,48 +356,49 @@ __global__ __launch_bounds__(256) void k_classify(int n_world, const int32_t* __
             r.x = (int)floor((g.x - Rp - g0) / h - 1e-4); r.y = (int)floor((g.x + Rp - g0) / h + 1e-4);
             r.z = (int)floor((g.z - Rp - g0) / h - 1e-4); r.w = (int)floor((g.z + Rp - g0) / h + 1e-4);
             r.x = max(0, r.x); r.z = max(0, r.z); r.y = min(G - 1, r.y); r.w = min(G - 1, r.w);
-            cnt = (r.y - r.x + 1) * (r.w - r.z + 1);
+            cx = r.y - r.x + 1; cz = r.w - r.z + 1;
+            bn.x = accel_fine_bin((double)g.x, g0, h, P.F, P.Gf); bn.y = accel_fine_bin((double)g.z, g0, h, P.F, P.Gf);
+            atomicAdd(&C->reg_cells, (unsigned long long)(cx * cz));
             atomicMin(&C->ylo, ord_of((double)g.y - Rp)); atomicMax(&C->yhi, ord_of((double)g.y + Rp)); atomicMax(&C->rmax, ord_of(Rp));
         }
     }
-    is_large[s] = large; nreg[s] = cnt; range[s] = r;
+    is_large[s] = large; nreg_x[s] = cx; nreg_z[s] = cz; range[s] = r; bins[s] = bn;
 }
 
-__global__ __launch_bounds__(256) void k_regs(int n_world, const int* __restrict__ nreg, const int* __restrict__ reg_off, const int4* __restrict__ range, int G,
-                                              unsigned long long* keys_x, unsigned long long* keys_z) {
+__global__ __launch_bounds__(256) void k_regs(int n_world, const int* __restrict__ nreg_x, const int* __restrict__ off_x, const int* __restrict__ off_z, const int4* __restrict__ range,
+                                              const int2* __restrict__ bins, int Gf, unsigned long long* keys_x, unsigned long long* keys_z) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_world || nreg[s] == 0) return;
+    if (s >= n_world || nreg_x[s] == 0) return;
     const int4 r = range[s];
-    size_t o = (size_t)reg_off[s];
-    for (int ix = r.x; ix <= r.y; ++ix)
-        for (int iz = r.z; iz <= r.w; ++iz) {
-            keys_x[o] = ((unsigned long long)(unsigned)(ix * G + iz) << 32) | (unsigned)s;
-            keys_z[o] = ((unsigned long long)(unsigned)(iz * G + ix) << 32) | (unsigned)s;
-            ++o;
-        }
+    const int2 bn = bins[s];
+    size_t o = (size_t)off_x[s];
+    for (int ix = r.x; ix <= r.y; ++ix) keys_x[o++] = ((unsigned long long)(unsigned)(ix * Gf + bn.y) << 32) | (unsigned)s;      // columns along x: keyed by the bin of cz
+    o = (size_t)off_z[s];
+    for (int iz = r.z; iz <= r.w; ++iz) keys_z[o++] = ((unsigned long long)(unsigned)(iz * Gf + bn.x) << 32) | (unsigned)s;
 }
 
-// entries of both grid copies from the sorted registrations; the cell starts by binary search
-__global__ __launch_bounds__(256) void k_fill(const unsigned long long* __restrict__ sx, const unsigned long long* __restrict__ sz, unsigned total,
+// entries of both grid copies from the sorted registrations; the bin starts by binary search
+__global__ __launch_bounds__(256) void k_fill(const unsigned long long* __restrict__ sx, const unsigned long long* __restrict__ sz, unsigned nx, unsigned nz,
                                               const float4* __restrict__ hot_of, const float4* __restrict__ sb_lo, const float4* __restrict__ sb_hi, float4* hot, float4* brick) {
     const unsigned a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= 2u * total + 16u) return;
-    if (a >= 2u * total) {                                              // pad entries that can never test positive (the walk over-reads)
+    const unsigned total = nx + nz;
+    if (a >= total + 16u) return;
+    if (a >= total) {                                                   // pad entries that can never test positive (the walk over-reads)
         const float qn = __builtin_nanf("");
         hot[a] = make_float4(qn, qn, qn, qn); brick[2 * (size_t)a] = make_float4(qn, qn, qn, 0.f); brick[2 * (size_t)a + 1] = make_float4(qn, qn, qn, qn);
         return;
     }
-    const int s = (int)(unsigned)(a < total ? sx[a] : sz[a - total]);
+    const int s = (int)(unsigned)(a < nx ? sx[a] : sz[a - nx]);
     hot[a] = hot_of[s]; brick[2 * (size_t)a] = sb_lo[s]; brick[2 * (size_t)a + 1] = sb_hi[s];
 }
-__global__ __launch_bounds__(256) void k_cellstarts(const unsigned long long* __restrict__ sx, const unsigned long long* __restrict__ sz, unsigned total, unsigned ncell, int32_t* cs) {
+__global__ __launch_bounds__(256) void k_cellstarts(const unsigned long long* __restrict__ sx, const unsigned long long* __restrict__ sz, unsigned nx, unsigned nz, unsigned nbin, int32_t* cs) {
     const unsigned c = blockIdx.x * 256 + threadIdx.x;
-    if (c > ncell) return;
+    if (c > nbin) return;
     for (int copy = 0; copy < 2; ++copy) {
         const unsigned long long* k = copy ? sz : sx;
-        unsigned lo = 0, hi = total;                                    // first registration with cell >= c
+        unsigned lo = 0, hi = copy ? nz : nx;                           // first registration with bin >= c
         while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if ((unsigned)(k[mid] >> 32) < c) lo = mid + 1; else hi = mid; }
-        cs[(size_t)copy * (ncell + 1) + c] = (int32_t)(copy ? total + lo : lo);
+        cs[(size_t)copy * (nbin + 1) + c] = (int32_t)(copy ? nx + lo : lo);
     }
 }
 __global__ __launch_bounds__(256) void k_large(int n_world, const int* __restrict__ is_large, const int* __restrict__ large_off, const float4* __restrict__ hot_of,
@@ -458,7 +462,7 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     // ---- workspace: everything whose size is known from n (freed at the end)
     const size_t cap = (size_t)16 * n + 65536;                         // (cell, sphere) pairs; more -> host build
     const size_t sort_tmp = (size_t)64 << 20;
-    const size_t ws_bytes = cap * 16 + (size_t)n * (16 * 4 + 4 * 8 + 16) + sort_tmp + ((size_t)1 << 20);
+    const size_t ws_bytes = cap * 16 + (size_t)n * (16 * 4 + 4 * 8 + 16 + 16) + sort_tmp + ((size_t)1 << 20);
     void* ws_mem = nullptr;
     RT_TRY(hipMalloc(&ws_mem, ws_bytes));
     struct Guard { void* p; ~Guard() { if (p) (void)hipFree(p); } } guard{ws_mem};
@@ -472,7 +476,7 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     unsigned long long* pairs_a = W.take<unsigned long long>(cap); unsigned long long* pairs_b = W.take<unsigned long long>(cap);
     float4* hot_of = W.take<float4>(n); float4* sb_lo = W.take<float4>(n); float4* sb_hi = W.take<float4>(n);
     int* multi = W.take<int>(n); int* row_of = W.take<int>(n); int* is_large = W.take<int>(n); int* large_off = W.take<int>(n);
-    int* nreg = W.take<int>(n); int* reg_off = W.take<int>(n); int4* range = W.take<int4>(n);
+    int* nreg_x = W.take<int>(n); int* nreg_z = W.take<int>(n); int* off_x = W.take<int>(n); int* off_z = W.take<int>(n); int4* range = W.take<int4>(n); int2* bins = W.take<int2>(n);
     unsigned* r2a = W.take<unsigned>(n); unsigned* r2b = W.take<unsigned>(n);
     void* tmp = W.take<char>(sort_tmp);
     if (W.used > W.size) return RT_ENOMEM;
@@ -608,63 +612,68 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     GridParams P; P.h = h; P.Rlim = 1.5 * h;
     const double half = kRootHalfXZ + 2.0 * P.Rlim + 2.0 * h;
     P.G = (int)std::ceil(2.0 * half / h); P.g0 = -half;
-    const int G = P.G;
-    hipLaunchKernelGGL(k_classify, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int32_t*)memb_start, (const float4*)hot_of, P, is_large, nreg, range, C);
+    P.F = RT_ACCEL_FINE; P.Gf = P.G * P.F;
+    const int G = P.G, Gf = P.Gf;
+    hipLaunchKernelGGL(k_classify, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int32_t*)memb_start, (const float4*)hot_of, P, is_large, nreg_x, nreg_z, range, bins, C);
     if ((rc = excl_scan(is_large, large_off, (size_t)n, tmp, sort_tmp, st))) return rc;
-    if ((rc = excl_scan(nreg, reg_off, (size_t)n, tmp, sort_tmp, st))) return rc;
-    int tail[4] = {0, 0, 0, 0};
+    if ((rc = excl_scan(nreg_x, off_x, (size_t)n, tmp, sort_tmp, st))) return rc;
+    if ((rc = excl_scan(nreg_z, off_z, (size_t)n, tmp, sort_tmp, st))) return rc;
+    int tail[6] = {0, 0, 0, 0, 0, 0};
     RT_TRY(hipMemcpyAsync(&tail[0], is_large + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
     RT_TRY(hipMemcpyAsync(&tail[1], large_off + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
-    RT_TRY(hipMemcpyAsync(&tail[2], nreg + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
-    RT_TRY(hipMemcpyAsync(&tail[3], reg_off + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    RT_TRY(hipMemcpyAsync(&tail[2], nreg_x + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    RT_TRY(hipMemcpyAsync(&tail[3], off_x + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    RT_TRY(hipMemcpyAsync(&tail[4], nreg_z + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    RT_TRY(hipMemcpyAsync(&tail[5], off_z + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
     RT_TRY(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
     RT_TRY(hipStreamSynchronize(st));                                   // (5) registrations, large spheres, y-slab
     const int n_large = tail[0] + tail[1];
-    const size_t total = (size_t)tail[2] + (size_t)tail[3];
-    const size_t ncell = (size_t)G * G;
+    const size_t nx = (size_t)tail[2] + (size_t)tail[3], nz = (size_t)tail[4] + (size_t)tail[5], total = nx + nz;
+    const size_t ncell = (size_t)G * G, nbin = (size_t)G * Gf;
     // ---- second part of the tree's allocation: the grid
-    const size_t b_bytes = (2 * total + 16) * (16 + 32) + 2 * (ncell + 1) * 4 + (size_t)std::max(1, n_large) * (16 + 32) + (size_t)std::max(1, bit_rows) * 64 + 2 * std::max<size_t>(total, 1) * 16 + 32 * 256;
+    const size_t b_bytes = (total + 16) * (16 + 32) + 2 * (nbin + 1) * 4 + (size_t)std::max(1, n_large) * (16 + 32) + (size_t)std::max(1, bit_rows) * 64 + (std::max<size_t>(nx, 1) + std::max<size_t>(nz, 1)) * 8 + 32 * 256;
     void* b_mem = nullptr;
     RT_TRY(hipMalloc(&b_mem, b_bytes));
     Z.d_acc[7] = b_mem;                                                 // freed with the other accel buffers
     Arena B; B.base = (char*)b_mem; B.size = b_bytes;
-    float4* g_hot = B.take<float4>(2 * total + 16); float4* g_brick = B.take<float4>(4 * total + 32);
-    int32_t* cs = B.take<int32_t>(2 * (ncell + 1));
+    float4* g_hot = B.take<float4>(total + 16); float4* g_brick = B.take<float4>(2 * total + 32);
+    int32_t* cs = B.take<int32_t>(2 * (nbin + 1));
     float4* large_hot = B.take<float4>(std::max(1, n_large)); float4* large_brick = B.take<float4>(2 * (size_t)std::max(1, n_large));
     uint32_t* cellbits = B.take<uint32_t>(16 * (size_t)std::max(1, bit_rows));
-    unsigned long long* kx = B.take<unsigned long long>(std::max<size_t>(total, 1)); unsigned long long* kz = B.take<unsigned long long>(std::max<size_t>(total, 1));
+    unsigned long long* kx = B.take<unsigned long long>(std::max<size_t>(nx, 1)); unsigned long long* kz = B.take<unsigned long long>(std::max<size_t>(nz, 1));
     if (B.used > B.size) return RT_ENOMEM;
     unsigned long long* kxs = pairs_a; unsigned long long* kzs = pairs_b;                       // sorted keys in the workspace (the pairs are done with)
-    if (total > cap) return RT_ENOTSUP;
+    if (nx > cap || nz > cap) return RT_ENOTSUP;
     RT_TRY(hipMemsetAsync(cellbits, 0, 64 * (size_t)std::max(1, bit_rows), st));
     RT_TRY(hipMemsetAsync(large_brick, 0, 32 * (size_t)std::max(1, n_large), st));
     hipLaunchKernelGGL(k_bitrows, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int32_t*)memb_start, (const int32_t*)memb_cell, (const int32_t*)devcell, (const int*)multi, (const int*)row_of, bits_index, cellbits);
     if (total) {
-        hipLaunchKernelGGL(k_regs, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int*)nreg, (const int*)reg_off, (const int4*)range, G, kx, kz);
-        const unsigned kb = 32 + bits_for((unsigned long long)ncell);
-        if ((rc = sort_keys(kx, kxs, total, 0, kb, tmp, sort_tmp, st))) return rc;
-        if ((rc = sort_keys(kz, kzs, total, 0, kb, tmp, sort_tmp, st))) return rc;
+        hipLaunchKernelGGL(k_regs, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int*)nreg_x, (const int*)off_x, (const int*)off_z, (const int4*)range, (const int2*)bins, Gf, kx, kz);
+        const unsigned kb = 32 + bits_for((unsigned long long)nbin);
+        if (nx && (rc = sort_keys(kx, kxs, nx, 0, kb, tmp, sort_tmp, st))) return rc;
+        if (nz && (rc = sort_keys(kz, kzs, nz, 0, kb, tmp, sort_tmp, st))) return rc;
     }
-    hipLaunchKernelGGL(k_fill, dim3(blocks_for(2 * total + 16)), dim3(256), 0, st, (const unsigned long long*)kxs, (const unsigned long long*)kzs, (unsigned)total,
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(total + 16)), dim3(256), 0, st, (const unsigned long long*)kxs, (const unsigned long long*)kzs, (unsigned)nx, (unsigned)nz,
                        (const float4*)hot_of, (const float4*)sb_lo, (const float4*)sb_hi, g_hot, g_brick);
-    hipLaunchKernelGGL(k_cellstarts, dim3(blocks_for(ncell + 1)), dim3(256), 0, st, (const unsigned long long*)kxs, (const unsigned long long*)kzs, (unsigned)total, (unsigned)ncell, cs);
+    hipLaunchKernelGGL(k_cellstarts, dim3(blocks_for(nbin + 1)), dim3(256), 0, st, (const unsigned long long*)kxs, (const unsigned long long*)kzs, (unsigned)nx, (unsigned)nz, (unsigned)nbin, cs);
     if (n_large) hipLaunchKernelGGL(k_large, dim3(blocks_for((size_t)n)), dim3(256), 0, st, n, (const int*)is_large, (const int*)large_off, (const float4*)hot_of,
                                     (const float4*)sb_lo, (const float4*)sb_hi, large_hot, large_brick);
     RT_TRY(hipGetLastError());
     RT_TRY(hipStreamSynchronize(st));                                   // the workspace is freed on return
     // ---- parameters, as build_accel
     p.large_hot = large_hot; p.large_brick = large_brick; p.cs = cs; p.hot = g_hot; p.brick = g_brick;
-    p.zoff = (int32_t)(ncell + 1);
+    p.zoff = (int32_t)(nbin + 1);
     p.memb_start = memb_start; p.memb_cell = memb_cell; p.bits_index = bits_index; p.cellbits = cellbits; p.cellnode = cellnode;
-    p.n_large = n_large; p.G = G; p.g0 = (float)P.g0; p.h = (float)h; p.inv_h = (float)(1.0 / h);
+    p.n_large = n_large; p.G = G; p.F = P.F; p.Gf = Gf; p.g0 = (float)P.g0; p.h = (float)h; p.inv_h = (float)(1.0 / h);
     double ylo = double_of(hc.ylo), yhi = double_of(hc.yhi), rmax = hc.rmax ? double_of(hc.rmax) : 0.0;
     if (total == 0 && hc.ylo == ~0ull) { ylo = 0; yhi = 0; rmax = 0; }
     p.ylo = (float)(ylo - 1e-4); p.yhi = (float)(yhi + 1e-4); p.rmax = (float)(rmax + 1e-4);
+    p.rq_c = accel_query_growth(rmax, h);
     p.zone2 = (float)(kZone * kZone);
     p.enabled = 1;
-    p.coop_groups = (double)total <= 8.0 * (double)ncell ? 4 : 1;
-    p.solo_chains = (double)total <= RT_SOLO_DENSITY * (double)ncell ? 1 : 0;
-    AH.p = p; AH.n_entries = total;
+    p.coop_groups = (double)hc.reg_cells <= 8.0 * (double)ncell ? 4 : 1;
+    p.solo_chains = (double)hc.reg_cells <= RT_SOLO_DENSITY * (double)ncell ? 1 : 0;
+    AH.p = p; AH.n_entries = nx; AH.n_entries_z = nz;
     Z.dev.acc = p;
     Z.uploaded = true;
     return 0;

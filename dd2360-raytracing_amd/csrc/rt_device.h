@@ -83,9 +83,12 @@ struct DevScene {
 struct DevAccel {
     const float4* large_hot;   // [n_large] (cx,cy,cz,r^2): tree spheres too big (or too far out) for the grid, always tested
     const float4* large_brick; // [2*n_large] as `brick`
-    // Two copies of the grid so that the cells a ray crosses inside one column of its major axis are contiguous:
-    // x-major (cell (ix,iz) at ix*G+iz) in cs[0 .. G*G], z-major (cell at iz*G+ix) in cs[zoff .. zoff+G*G];
-    // cs values index hot[] / id[] directly (the z-major copy's entries follow the x-major copy's).
+    // The grid: columns of width h along a ray's major axis, each sphere registered ONCE in every column its inflated extent
+    // overlaps, a column's entries sorted by the sphere's CENTRE along the minor axis into Gf = G * F fine bins (bin width h / F).
+    // A ray asks a column for the bins its line crosses grown by the largest inflated radius (rq_c, in cell units) — the
+    // inflation sits in the query, not in the registration, so no sphere appears twice in a column's range.
+    // Two copies: columns along x (bin (ix, fz) at ix*Gf + fz) in cs[0 .. G*Gf], columns along z (bin (iz, fx) at iz*Gf + fx) in
+    // cs[zoff .. zoff + G*Gf]; cs values index hot[] / brick[] directly (the z copy's entries follow the x copy's).
     const int32_t* cs;
     const float4* hot;         // (cx,cy,cz,r^2)
     // per entry two float4: (lo.x, lo.y, lo.z, bits of the world-list index), (hi.x, hi.y, hi.z, bits of node1) —
@@ -99,6 +102,8 @@ struct DevAccel {
     const uint32_t* cellbits;  // rows of 16 words: bit (ix*64 + iy*8 + iz) set = the sphere is stored in that level-3 cell
     const int32_t* cellnode;   // [512] level-3 cell (ix*64 + iy*8 + iz of the root box's 8x8x8 grid) -> pre-order node index, or -1
     int32_t n_large, G;
+    int32_t F, Gf;             // fine bins per cell along a column's minor axis, G * F
+    float rq_c;                // query growth in cell units: (largest inflated radius + walk slack) / h
     float g0, h, inv_h;        // grid origin (same for x and z), cell size
     float ylo, yhi;            // y-slab covering every grid sphere's inflated ball
     float rmax;                // largest inflated radius R' of a grid sphere

@@ -426,22 +426,6 @@ RT_DEV Walk walk_setup(const DevAccel& A, const RayF& r, float best_t, int best)
     return W;
 }
 
-// entry range [e0, e1) of the cells the line can touch inside column `col` (cell units, lower edge at col)
-RT_DEV void column_range(const DevAccel& A, const Walk& W, int col, int& e0, int& e1) {
-    const int G = A.G;
-    const float fG = (float)G, s_c = 2e-3f * A.inv_h;
-    const float u0 = W.on_c + ((float)col - W.om_c) * W.slope, u1 = u0 + W.slope;
-    const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-    int k0 = (int)floorf(fminf(fmaxf(lo, -1.0f), fG)), k1 = (int)floorf(fminf(fmaxf(hi, -1.0f), fG));
-    e0 = 0; e1 = 0;
-    if (!(k1 < 0 || k0 > G - 1)) {
-        k0 = max(k0, 0); k1 = min(k1, G - 1);
-        const int cbase = W.coff + col * G;
-        e0 = A.cs[cbase + k0];
-        e1 = A.cs[cbase + k1 + 1];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------- the walk of a full wave
 // Letting every lane test the spheres of ITS columns (rounds 1-2: walk_lanes, removed in round 3 with the cooperative single-ray
 // walk once no launch reached them) ran at 47 % busy lanes, 3.5 of 6 test slots used, lanes holding a candidate waiting for a
@@ -538,8 +522,9 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
     const int32_t* __restrict__ cs = A.cs;
     const float4* __restrict__ hot = A.hot;
     const int lane = threadIdx.x & 63;
-    const int G = A.G;
-    const float fG = (float)G, fGm = fG - 0.5f, s_c = 2e-3f * A.inv_h;
+    // a column's bins (rt_accel.h): Gf fine bins of width 1 / F cells, entries keyed by their centre — the query grows by q_c
+    const int Gf = A.Gf;
+    const float fF = (float)A.F, fGf = (float)Gf, fGfm = fGf - 0.5f, q_c = A.rq_c;
     const int step = W.fwd ? 1 : -1;
     const float f_atm = a * (0.001f * 0.9999f - 1e-6f);
     bool walking = W.walking && W.i != W.iend;
@@ -562,10 +547,10 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
             if (c < cols_now && walking && W.i != W.iend) {
                 STAT(st, ST_COLS, 1);
                 const float u0 = W.on_c + ((float)W.i - W.om_c) * W.slope, u1 = u0 + W.slope;
-                const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-                if (hi >= 0.0f && lo < fG) {
-                    const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGm);
-                    const unsigned cbase = (unsigned)(W.coff + W.i * G);
+                const float lo = (fminf(u0, u1) - q_c) * fF, hi = (fmaxf(u0, u1) + q_c) * fF;      // in fine bins (F is a power of two)
+                if (hi >= 0.0f && lo < fGf) {
+                    const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGfm);
+                    const unsigned cbase = (unsigned)(W.coff + W.i * Gf);
                     e0[c] = cs[cbase + (unsigned)k0]; e1[c] = cs[cbase + (unsigned)k1 + 1u];
                 }
                 W.i += step; ++W.cols;
@@ -721,8 +706,8 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
     const int32_t* __restrict__ cs = A.cs;
     const float4* __restrict__ hot = A.hot;
     const int lane = threadIdx.x & 63;
-    const int G = A.G;
-    const float fG = (float)G, fGm = fG - 0.5f, s_c = 2e-3f * A.inv_h;
+    const int Gf = A.Gf;
+    const float fF = (float)A.F, fGf = (float)Gf, fGfm = fGf - 0.5f, q_c = A.rq_c;
     const int step = W.fwd ? 1 : -1;
     bool walking = W.walking && W.i != W.iend;
     const int nw0 = __popcll(__ballot(walking));
@@ -737,10 +722,10 @@ RT_DEV void walk_pool_dense(const DevTree& T, const float4* s_nodes, WalkLds& L,
         if (walking && W.i != W.iend) {
             STAT(st, ST_COLS, 1);
             const float u0 = W.on_c + ((float)W.i - W.om_c) * W.slope, u1 = u0 + W.slope;
-            const float lo = fminf(u0, u1) - s_c, hi = fmaxf(u0, u1) + s_c;
-            if (hi >= 0.0f && lo < fG) {
-                const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGm);
-                const unsigned cbase = (unsigned)(W.coff + W.i * G);
+            const float lo = (fminf(u0, u1) - q_c) * fF, hi = (fmaxf(u0, u1) + q_c) * fF;
+            if (hi >= 0.0f && lo < fGf) {
+                const int k0 = (int)fmaxf(lo, 0.0f), k1 = (int)fminf(hi, fGfm);
+                const unsigned cbase = (unsigned)(W.coff + W.i * Gf);
                 e0 = cs[cbase + (unsigned)k0]; e1 = cs[cbase + (unsigned)k1 + 1u];
             }
             W.i += step; ++W.cols;
