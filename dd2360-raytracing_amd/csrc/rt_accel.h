@@ -5,9 +5,12 @@
 // gives the same record as long as every skipped sphere is one whose float sphere::hit (sphere.h:17-46) cannot
 // succeed with a smaller t.  For binary32 arithmetic in the reference's operation order,
 //     discriminant > 0   ==>   dist(centre, line)^2  <  r^2 + 16.1 u |o - c|^2        (u = 2^-24)
-// so a sphere whose ball of radius R = sqrt(r^2 + K2) (K2 covers 16.1 u |o-c|^2 for every ray origin inside the "near
-// zone") is missed by the ray's line cannot be hit.  The grid below registers each small sphere in every (x,z) cell its
-// ball, grown by a rasterisation slack, can touch; the kernel walks the cells the ray's (x,z) projection crosses.
+// so a sphere whose ball of radius R = sqrt(r^2 + K2) (K2 covers 16.1 u |o-c|^2 for every ray origin inside the "near zone") is
+// missed by the ray's line cannot be hit, and the float hit point of a sphere that is hit lies within R' of its centre.  The grid
+// files each small sphere under every column (width h along a ray's major axis) its inflated extent overlaps, and inside a column
+// under the fine bin (h / F) of its CENTRE's other coordinate.  The kernel walks the columns in which hit points can lie — from the
+// origin's to the best hit's — and reads in each the bins between the line's extreme positions inside the column, grown by R'
+// (DESIGN.md App. A.2): a sphere is read in the column of its own hit point, and never twice in one column.
 // Rays outside the near zone, rays with a zero direction component, and exact-t ties fall back to the reference scan.
 #pragma once
 #include <vector>
@@ -56,12 +59,7 @@ constexpr double kSlack = 2e-3;         // rasterisation slack (absorbs float er
 // rounded up.  (0.012 cost 2.7 % of the C3 frame: the lowest 3 % of a sphere resting on y = 0 fell outside its brick.)
 constexpr double kBrickMxz = 0.0008, kBrickMy = 0.0085;
 // 16.1 u |o-c|^2 with |o-c| <= kZone + kCentreBound, times a safety factor of 2
-#ifndef RT_ACCEL_FINE
-#define RT_ACCEL_FINE 4          // fine bins per cell along a column (a power of two)
-#endif
-#ifndef RT_DENSE_CELL
-#define RT_DENSE_CELL 0.7
-#endif
+constexpr double kSparseCell = RT_SPARSE_CELL;   // column width of sparse scenes, in units of 2 R'
 constexpr double kDenseCell = RT_DENSE_CELL;     // cell size of dense scenes, in units of 2 R' (build_accel step 2, and the device build)
 __host__ __device__ inline double accel_K2() { const double u = 5.9604644775390625e-8, d = kZone + kCentreBound; return 2.0 * 16.1 * u * d * d; }
 // inflated radius of the ball a ray must cross for the float test to be able to succeed, plus the walk's slack
@@ -162,11 +160,10 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     double h = 2.0 * accel_Rp(rmed * rmed);
     h = std::min(1.0, std::max(0.05, h));
     {
-        // dense scenes (a sphere covers ~4 cells of size 2R': more than 8 entries per cell expected) take cells of 1.4 R':
-        // tests per ray go with the cell size, columns per ray against it (C5, 37 per cell: 129.5 -> 122.4 ms at 0.7, 125.4 at
-        // 0.5; C3, 3.6 per cell: 22.7 -> 23.2 ms at 0.7, so sparse scenes keep 2R')
+        // dense scenes (a sphere's inflated square covers ~4 cells of size 2R': more than 8 per cell expected) take narrower columns:
+        // a ray that hits within its first column tests what that column holds; sparse scenes walk many columns per ray
         const double g = std::ceil(2.0 * (kRootHalfXZ + 5.0 * h) / h);
-        if (4.0 * (double)radii.size() > 8.0 * g * g) h = std::max(0.05, kDenseCell * h);
+        h = std::max(0.05, (4.0 * (double)radii.size() > 8.0 * g * g ? kDenseCell : kSparseCell) * h);
     }
     const double Rlim = 1.5 * h;                               // spheres with R' above this go to the large list
     // extent: the reference's root box in x and z (every tree sphere's centre lies in it, grown by its radius); a list may
@@ -184,7 +181,7 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
     const int G = (int)std::ceil(2.0 * half / h);
     const double g0 = -half;
     p.G = G; p.g0 = (float)g0; p.h = (float)h; p.inv_h = (float)(1.0 / h);
-    // 3. classify + register.  A grid sphere goes ONCE into every column its inflated extent overlaps, keyed by the fine bin of its
+    // 3. classify + register.  A grid sphere goes once into every column its inflated extent overlaps, keyed by the fine bin of its
     // CENTRE along the column (accel_fine_bin): the walk grows its query by the largest inflated radius instead (DevAccel::rq_c).
     const int F = RT_ACCEL_FINE, Gf = G * F;
     p.F = F; p.Gf = Gf;
@@ -205,9 +202,9 @@ inline void build_accel(AccelHost& A, const std::vector<DevNode>& nodes, const s
         r.ix0 = (int)std::floor((g.x - Rp - g0) / h - 1e-4); r.ix1 = (int)std::floor((g.x + Rp - g0) / h + 1e-4);
         r.iz0 = (int)std::floor((g.z - Rp - g0) / h - 1e-4); r.iz1 = (int)std::floor((g.z + Rp - g0) / h + 1e-4);
         r.ix0 = std::max(0, r.ix0); r.iz0 = std::max(0, r.iz0); r.ix1 = std::min(G - 1, r.ix1); r.iz1 = std::min(G - 1, r.iz1);
+        cells += (double)(r.ix1 - r.ix0 + 1) * (double)(r.iz1 - r.iz0 + 1);
         r.bx = accel_fine_bin((double)g.x, g0, h, F, Gf); r.bz = accel_fine_bin((double)g.z, g0, h, F, Gf);
         regs.push_back(r);
-        cells += (double)(r.ix1 - r.ix0 + 1) * (double)(r.iz1 - r.iz0 + 1);
         ylo = std::min(ylo, (double)g.y - Rp); yhi = std::max(yhi, (double)g.y + Rp); rmax = std::max(rmax, Rp);
     }
     p.n_large = (int)A.large_id.size();

@@ -356,9 +356,9 @@ __global__ __launch_bounds__(256) void k_classify(int n_world, const int32_t* __
             r.x = (int)floor((g.x - Rp - g0) / h - 1e-4); r.y = (int)floor((g.x + Rp - g0) / h + 1e-4);
             r.z = (int)floor((g.z - Rp - g0) / h - 1e-4); r.w = (int)floor((g.z + Rp - g0) / h + 1e-4);
             r.x = max(0, r.x); r.z = max(0, r.z); r.y = min(G - 1, r.y); r.w = min(G - 1, r.w);
+            atomicAdd(&C->reg_cells, (unsigned long long)((r.y - r.x + 1) * (r.w - r.z + 1)));
             cx = r.y - r.x + 1; cz = r.w - r.z + 1;
             bn.x = accel_fine_bin((double)g.x, g0, h, P.F, P.Gf); bn.y = accel_fine_bin((double)g.z, g0, h, P.F, P.Gf);
-            atomicAdd(&C->reg_cells, (unsigned long long)(cx * cz));
             atomicMin(&C->ylo, ord_of((double)g.y - Rp)); atomicMax(&C->yhi, ord_of((double)g.y + Rp)); atomicMax(&C->rmax, ord_of(Rp));
         }
     }
@@ -608,7 +608,7 @@ int build(rt_octree* O, const float4* d_geom, const int32_t* d_kind, int n, int 
     const double rmed = std::sqrt((double)med_r2);
     double h = 2.0 * accel_Rp(rmed * rmed);
     h = std::min(1.0, std::max(0.05, h));
-    { const double g = std::ceil(2.0 * (kRootHalfXZ + 5.0 * h) / h); if (4.0 * (double)in_tree > 8.0 * g * g) h = std::max(0.05, kDenseCell * h); }
+    { const double g = std::ceil(2.0 * (kRootHalfXZ + 5.0 * h) / h); h = std::max(0.05, (4.0 * (double)in_tree > 8.0 * g * g ? kDenseCell : kSparseCell) * h); }
     GridParams P; P.h = h; P.Rlim = 1.5 * h;
     const double half = kRootHalfXZ + 2.0 * P.Rlim + 2.0 * h;
     P.G = (int)std::ceil(2.0 * half / h); P.g0 = -half;

@@ -104,6 +104,20 @@
 #define RT_SPLIT_WC 0
 #endif
 
+// ---- the candidate grid (rt_accel.h; host build, device build and the walks read these) ----------------------------------------------
+// (measured and not kept, round 4: a sphere filed ONCE, under the column of its centre, the walk reaching R' beyond its first and last
+// column and following the line R' beyond a column's edges — no sphere twice per ray, half the entries: C5 393 ms against 354, C3 14.60
+// against 14.25: the extra column at either end of every walk costs more than the duplicates)
+#ifndef RT_ACCEL_FINE
+#define RT_ACCEL_FINE 8         // fine bins per cell along a column (a power of two).  C5 (before / after the tight column range): 2: 486 ms, 4: 462 / 359, 8: 450 / 352, 16: - / 349; C3 2: 15.23, 4: 15.01 / 14.16, 8: 14.88 / 14.05, 16: - / 14.02
+#endif
+#ifndef RT_DENSE_CELL
+#define RT_DENSE_CELL 0.7       // column width of dense scenes, in units of 2 R'.  C5 (before / after the tight column range): 0.5: 497 / 354 ms, 0.7: 462 / 352, 0.85: - / 359, 1.0: 467 / 368, 1.4: 526
+#endif
+#ifndef RT_SPARSE_CELL
+#define RT_SPARSE_CELL 1.0      // ... of sparse scenes.  C3 (before / after the tight column range): 0.7: 15.17 / 14.17 ms, 1.0: 15.01 / 14.05, 1.4: 14.80 / 14.12, 2.0: 15.25; C2: 0.7: 10.96, 1.0: 10.52, 1.4: 10.24
+#endif
+
 // ---- the pooled walks -----------------------------------------------------------------------------------
 #ifndef RT_QUORUM_SPARSE
 #define RT_QUORUM_SPARSE 4      // walk_pool returns when 1/4 of the walkers that entered are left.  C3: off 21.06 ms, 2: 20.14, 3: 19.91, 4: 19.94, 8: 20.41
