@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
         while (slot < n_slots) {
             // Slots are interleaved over blocks of 64 tiles (in hand-out order): consecutive slots are the same pixel
             // position of 64 different tiles, so the pixels of one tile (long chains cluster) never travel together.
-            // The END of the queue is handed out per pixel, most expensive 2x2 pilot block first (k_tail_order): a launch with few pixels
+            // The END of the queue is handed out per pixel, most expensive 2x2 pilot block first (k_tail_hist / k_tail_scatter): a launch with few pixels
             // per lane ends when its last-started pixels do, and inside a tile of a cheap class sit pixels of three times its mean.
             long long local_tile; int l;
             const long long tail0 = (MODE == 0 && A.tail_list) ? (long long)A.queue[kQueueThr + 2] : 0;
@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
             }
             sum += v;
         }
-    if (sum8) sum8[g] = (unsigned char)(sum < 255 ? sum : 255);                    // for k_tail_order
+    if (sum8) sum8[g] = (unsigned char)(sum < 255 ? sum : 255);                    // for the tail sort (k_tail_hist / k_tail_scatter)
     // (k_tile_order, which runs first, may have lowered the threshold: a chain is long relative to the launch's load per lane)
     const int abs_sum = (int)A.queue[kQueueThr + 1];
     const bool is_long = sum >= (abs_sum > 0 && abs_sum < long_sum ? abs_sum : long_sum);
@@ -1553,7 +1553,8 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
 // unless it runs in a thin wave from early on; whether 3000 bounces are long depends on the launch (C5 whole frame: load 18 000;
 // one part of eight: 2 250).  queue[kQueueThr] = in-flight threshold in iterations, queue[kQueueThr + 1] = the same as a 3x3 pilot sum (18 samples).
 __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n, unsigned int* __restrict__ queue,
-                                                    int ns, int n_lanes, float f_inflight, float f_static, float f_tail, long long tail_cap_tiles) {
+                                                    int ns, int n_lanes, float f_inflight, float f_static, float f_tail, long long tail_cap_tiles, unsigned int* __restrict__ tail_ws) {
+    if (tail_ws && threadIdx.x < 512) tail_ws[threadIdx.x] = 0u;   // (the tail sort's counts and cursors: k_tail_hist / k_tail_scatter run after this kernel)
     __shared__ int s_cnt[16][8];
     __shared__ long long s_sum[16];
     __shared__ long long s_ccost[16][8];
@@ -1563,12 +1564,19 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long csum = 0;
     long long ccost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long t = lo + lane; t < hi; t += 64) {
-        const int w = cost[t];
-        const int c = cost_class(w);
-        csum += w;
+    // (eight loads in flight per lane: one block sorts the whole frame's tiles, and a pass of dependent round trips per 64 tiles is what it costs)
+    for (long long t0 = lo + lane; t0 < hi; t0 += 512) {
+        int wv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { cnt[k] += (c == k) ? 1 : 0; ccost[k] += (c == k) ? w : 0; }
+        for (int u = 0; u < 8; ++u) wv[u] = (t0 + 64 * u < hi) ? cost[t0 + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = wv[u] < 0 ? 0 : wv[u];
+            const int c = wv[u] < 0 ? -1 : cost_class(w);
+            csum += w;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { cnt[k] += (c == k) ? 1 : 0; ccost[k] += (c == k) ? w : 0; }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1592,14 +1600,16 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
         if (ti < (double)RT_LONG_RATE_MIN * ns) ti = (double)RT_LONG_RATE_MIN * ns;
         if (tsum < (double)RT_PILOT_LONG_SUM_MIN) tsum = (double)RT_PILOT_LONG_SUM_MIN;
         // the tail of the queue: the last tiles of the order that hold f_tail of the predicted work (tiles of one class taken as alike),
-        // from a multiple of 64 on — their pixels are handed out by k_tail_order's list
+        // from a multiple of 64 on — their pixels are handed out by the tail sort's list (k_tail_hist / k_tail_scatter)
         unsigned int tail_mark = 0u;
         if (f_tail > 0.f && tot > 0) {
             const double want = (1.0 - (double)f_tail) * (double)tot;
             double cum = 0.0; long long r0 = n;
             long long start = 0;
+#pragma unroll 1
             for (int k = 7; k >= 0; --k) {
                 long long nk = 0, ck = 0;
+#pragma unroll 1
                 for (int w = 0; w < 16; ++w) { nk += s_cnt[w][k]; ck += s_ccost[w][k]; }
                 if (nk > 0 && cum + (double)ck >= want) { r0 = start + (long long)((want - cum) / ((double)ck / (double)nk)); break; }
                 cum += (double)ck; start += nk;
@@ -1611,53 +1621,116 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
         queue[kQueueThr] = f_inflight > 0.f ? (unsigned int)(ti < 1.0 ? 1.0 : (ti > 4.0e9 ? 4.0e9 : ti)) : 0u;
         queue[kQueueThr + 1] = f_static > 0.f ? (unsigned int)(tsum < 1.0 ? 1.0 : (tsum > 1.0e9 ? 1.0e9 : tsum)) : 0u;
     }
-    long long base[8];
-    long long run = 0;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) {                                 // class k: after every higher class, behind the earlier waves' share
-        long long before = 0, all = 0;
-        for (int w = 0; w < 16; ++w) { const int v = s_cnt[w][k]; all += v; if (w < wave) before += v; }
-        base[k] = run + before; run += all;
+    // class k: after every higher class, behind the earlier waves' share.  (Computed by 128 threads into LDS: with every thread summing
+    // the 16 x 8 counts itself the kernel needed 1.1 KB of scratch per lane — for a grid of one block the runtime still sets scratch
+    // aside for the whole chip, on a slow path that cost ~80 us a launch.)
+    __shared__ int s_tot[8];
+    __shared__ int s_base[16][8];
+    if (threadIdx.x < 8) {
+        int all = 0;
+#pragma unroll 1
+        for (int w = 0; w < 16; ++w) all += s_cnt[w][threadIdx.x];
+        s_tot[threadIdx.x] = all;
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (long long t0 = lo; t0 < hi; t0 += 64) {
-        const long long t = t0 + lane;
-        const int c = t < hi ? cost_class(cost[t]) : -1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int w0 = threadIdx.x >> 3, k0 = threadIdx.x & 7;
+        int b = 0;
+#pragma unroll 1
+        for (int k = k0 + 1; k < 8; ++k) b += s_tot[k];
+#pragma unroll 1
+        for (int w = 0; w < w0; ++w) b += s_cnt[w][k0];
+        s_base[w0][k0] = b;
+    }
+    __syncthreads();
+    int base[8];                                                   // (positions: the frame's tiles fit 31 bits many times over)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned long long m = __ballot(c == k);
-            if (c == k) order[base[k] + __popcll(m & lt)] = (unsigned int)t;
-            base[k] += __popcll(m);
+    for (int k = 0; k < 8; ++k) base[k] = s_base[wave][k];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (long long t0 = lo; t0 < hi; t0 += 512) {
+        int wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = (t0 + 64 * u + lane < hi) ? cost[t0 + 64 * u + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t0 + 64 * u >= hi) break;                           // (wave-uniform)
+            const long long t = t0 + 64 * u + lane;
+            const int c = wv[u] < 0 ? -1 : cost_class(wv[u]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned long long m = __ballot(c == k);
+                if (c == k) order[base[k] + __popcll(m & lt)] = (unsigned int)t;
+                base[k] += __popcll(m);
+            }
         }
     }
 }
 
 // The pixels of the queue's tail (tiles of rank >= R0 in the hand-out order), sorted by the pilot's count for their 2x2 block and its
-// eight neighbours (k_long_select's sum8), most expensive first: one block, a counting sort over the 256 values.  Which lane renders a
-// pixel and when never changes the pixel; the order inside one value is left to the atomics.
-__global__ __launch_bounds__(1024) void k_tail_order(const unsigned int* __restrict__ order, const unsigned char* __restrict__ sum8, unsigned int* __restrict__ tail_list,
-                                                    long long n, const unsigned int* __restrict__ queue) {
+// eight neighbours (k_long_select's sum8), most expensive first: a counting sort over the 256 values in two launches of many blocks
+// (k_tail_hist: the histogram; k_tail_scatter: every block ranks its 1024 blocks among themselves in LDS and reserves its stretch of
+// each value's range with one atomic) — as one block of 1024 threads it took 158 us of C3's 14.5 ms step, whatever its inner loop did.
+// ws: 256 counts + 256 cursors, zeroed by k_tile_order.  Which lane renders a pixel and when never changes the pixel; the order inside
+// one value is left to the atomics.
+constexpr int kTailChunk = 1024;                                     // 2x2 blocks per thread block (four per thread)
+RT_DEV int tail_key(const unsigned int* __restrict__ order, const unsigned char* __restrict__ sum8, long long r0, long long b, long long n_blocks, long long& tile) {
+    tile = b < n_blocks ? (long long)order[r0 + (b >> 4)] : -1;
+    return tile >= 0 ? 255 - (int)sum8[tile * 16 + (b & 15)] : -1;
+}
+__global__ __launch_bounds__(256) void k_tail_hist(const unsigned int* __restrict__ order, const unsigned char* __restrict__ sum8, long long n, const unsigned int* __restrict__ queue, unsigned int* __restrict__ ws) {
     __shared__ unsigned int s_bin[256];
     const unsigned int mark = queue[kQueueThr + 2];
     if (mark == 0u) return;
-    const long long r0 = (long long)(mark - 1u) / 64;
-    const long long n_blocks = (n - r0) * 16;                        // 2x2 blocks of the tail tiles
-    for (int k = threadIdx.x; k < 256; k += 1024) s_bin[k] = 0u;
+    const long long r0 = (long long)(mark - 1u) / 64, n_blocks = (n - r0) * 16;
+    const long long b0 = (long long)blockIdx.x * kTailChunk;
+    if (b0 >= n_blocks) return;
+    s_bin[threadIdx.x] = 0u;
     __syncthreads();
-    for (long long b = threadIdx.x; b < n_blocks; b += 1024) {
-        const long long tile = (long long)order[r0 + (b >> 4)];
-        atomicAdd(&s_bin[255 - sum8[tile * 16 + (b & 15)]], 4u);
-    }
+    int key[4]; long long tile;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) key[u] = tail_key(order, sum8, r0, b0 + 256 * u + threadIdx.x, n_blocks, tile);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (key[u] >= 0) atomicAdd(&s_bin[key[u]], 4u);
     __syncthreads();
-    if (threadIdx.x == 0) { unsigned int run = 0u; for (int k = 0; k < 256; ++k) { const unsigned int c = s_bin[k]; s_bin[k] = run; run += c; } }
+    const unsigned int c = s_bin[threadIdx.x];
+    if (c != 0u) atomicAdd(&ws[threadIdx.x], c);
+}
+__global__ __launch_bounds__(256) void k_tail_scatter(const unsigned int* __restrict__ order, const unsigned char* __restrict__ sum8, unsigned int* __restrict__ tail_list,
+                                                     long long n, const unsigned int* __restrict__ queue, unsigned int* __restrict__ ws) {
+    __shared__ unsigned int s_bin[256], s_base[256], s_wave[4];
+    const unsigned int mark = queue[kQueueThr + 2];
+    if (mark == 0u) return;
+    const long long r0 = (long long)(mark - 1u) / 64, n_blocks = (n - r0) * 16;
+    const long long b0 = (long long)blockIdx.x * kTailChunk;
+    if (b0 >= n_blocks) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_bin[threadIdx.x] = 0u;
+    // where value `threadIdx.x` begins in the list: exclusive prefix over the 256 counts (a scan per wave, then the waves' totals)
+    const unsigned int cnt = ws[threadIdx.x];
+    unsigned int wtot;
+    const unsigned int ex = walk_excl_scan(cnt, wtot);
+    if (lane == 0) s_wave[wave] = wtot;
+    int key[4]; long long tile[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) key[u] = tail_key(order, sum8, r0, b0 + 256 * u + threadIdx.x, n_blocks, tile[u]);
     __syncthreads();
-    for (long long b = threadIdx.x; b < n_blocks; b += 1024) {
-        const long long tile = (long long)order[r0 + (b >> 4)];
-        const int sub = (int)(b & 15);
-        const unsigned int pos = atomicAdd(&s_bin[255 - sum8[tile * 16 + sub]], 4u);
+    unsigned int start = ex;
+    for (int w = 0; w < wave; ++w) start += s_wave[w];
+    unsigned int local[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) local[u] = key[u] >= 0 ? atomicAdd(&s_bin[key[u]], 4u) : 0u;
+    __syncthreads();
+    const unsigned int mine = s_bin[threadIdx.x];
+    s_base[threadIdx.x] = mine != 0u ? start + atomicAdd(&ws[256 + threadIdx.x], mine) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (key[u] < 0) continue;
+        const int sub = (int)((b0 + 256 * u + threadIdx.x) & 15);
+        const unsigned int pos = s_base[key[u]] + local[u];
         const int lx = 2 * (sub & 3), ly = 2 * (sub >> 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tail_list[pos + q] = (unsigned int)(tile * 64 + (ly + (q >> 1)) * 8 + lx + (q & 1));
+        for (int q = 0; q < 4; ++q) tail_list[pos + q] = (unsigned int)(tile[u] * 64 + (ly + (q >> 1)) * 8 + lx + (q & 1));
     }
 }
 #endif
@@ -1832,14 +1905,18 @@ const char* render_kernel_name(bool tree, int mode, const DevAccel& acc) {
 hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int* order, unsigned char* flags, unsigned int* long_list, hipStream_t st, int long_sum, int solo_sum) {
     // (the order kernel first: it also derives the launch's thresholds for long chains, which the selection reads)
     // flags: 64 bytes per local tile (one per pixel), 16 (the pilot's count per 2x2 block), 16 (that count summed over the block's 3x3 neighbourhood)
-    const bool tail = flags && A.tail_list && A.f_tail > 0.f;
+    const bool tail = flags && A.tail_list && A.tail_ws && A.f_tail > 0.f;
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles, A.queue, (int)A.ns, (int)A.n_lanes, A.f_inflight, A.f_static,
-                       tail ? A.f_tail : 0.f, (long long)A.n_local_tiles);
+                       tail ? A.f_tail : 0.f, (long long)A.n_local_tiles, tail ? A.tail_ws : (unsigned int*)nullptr);
     if (flags) {
         const unsigned char* pilot = flags + (size_t)A.n_local_tiles * 64;
         unsigned char* sum8 = flags + (size_t)A.n_local_tiles * 80;
         hipLaunchKernelGGL(k_long_select, dim3((unsigned)((A.n_local_tiles * 16 + 255) / 256)), dim3(256), 0, st, A, pilot, flags, long_list, long_sum > 0 ? long_sum : RT_PILOT_LONG_SUM, solo_sum, sum8);
-        if (tail) hipLaunchKernelGGL(k_tail_order, dim3(1), dim3(1024), 0, st, (const unsigned int*)order, (const unsigned char*)sum8, (unsigned int*)A.tail_list, (long long)A.n_local_tiles, (const unsigned int*)A.queue);
+        if (tail) {
+            const unsigned nb = (unsigned)((A.n_local_tiles * 16 + kTailChunk - 1) / kTailChunk);      // (the tail's size is known on the device only: blocks beyond it return at once)
+            hipLaunchKernelGGL(k_tail_hist, dim3(nb), dim3(256), 0, st, (const unsigned int*)order, (const unsigned char*)sum8, (long long)A.n_local_tiles, (const unsigned int*)A.queue, A.tail_ws);
+            hipLaunchKernelGGL(k_tail_scatter, dim3(nb), dim3(256), 0, st, (const unsigned int*)order, (const unsigned char*)sum8, (unsigned int*)A.tail_list, (long long)A.n_local_tiles, (const unsigned int*)A.queue, A.tail_ws);
+        }
     }
     return hipGetLastError();
 }

@@ -41,7 +41,7 @@
 #endif
 #ifndef RT_F_TAIL
 #define RT_F_TAIL 0.15f         // share of a launch's predicted work whose pixels are handed out one by one, most expensive 2x2 pilot block first, at the end of the
-#endif                          // queue (k_tail_order) instead of tile by tile; 0 = off
+#endif                          // queue (k_tail_hist / k_tail_scatter) instead of tile by tile; 0 = off
 // Consecutive pixel slots are the same pixel position of RT_INTERLEAVE different tiles (in hand-out order): long pixels cluster, and a tile's
 // pixels should not travel together — but rays of neighbouring pixels meet the same spheres, and a wave whose lanes hold 64 different tiles
 // finds nothing in its cache.  64: a tile's 64 pixels start in 64 waves; 16: in sixteen, four pixels of the tile each.
