@@ -469,13 +469,9 @@ RT_DEV unsigned walk_excl_scan(unsigned v, unsigned& total) {
 }
 
 // one queued candidate: sphere.h:24-43's offer, eligibility as in `offer`, merged into the owner's key
-RT_DEV void pool_candidate(const DevTree& T, const float4* s_nodes, WalkLds& L, const uint4 c STAT_ARG) {
-    const DevAccel& A = T.acc;
-    const int owner = (int)c.w, e = (int)c.z;
+RT_DEV void pool_candidate_b(const DevTree& T, const float4* s_nodes, WalkLds& L, const uint4 c, const float4 blo, const float4 bhi STAT_ARG) {
+    const int owner = (int)c.w;
     const float b = __uint_as_float(c.x), disc = __uint_as_float(c.y);
-    // (the brick is asked for before the roots are formed: its round trip overlaps the square root and the divisions — a candidate that
-    // cannot win has fetched it for nothing, a chain alone in its wave has one dependent round trip less per candidate)
-    const float4 blo = A.brick[2 * e], bhi = A.brick[2 * e + 1];
     const float4 r0 = L.ray[2 * owner], r1 = L.ray[2 * owner + 1];
     RayF q; q.o = {r0.x, r0.y, r0.z}; q.d = {r0.w, r1.x, r1.y};
     const float a = r1.z;
@@ -507,6 +503,14 @@ RT_DEV void pool_candidate(const DevTree& T, const float4* s_nodes, WalkLds& L, 
         }
     } else tie = id != best && best > 0;
     if (tie) { if (owner < 32) atomicOr(&L.tie_lo, 1u << owner); else atomicOr(&L.tie_hi, 1u << (owner - 32)); }
+}
+
+RT_DEV void pool_candidate(const DevTree& T, const float4* s_nodes, WalkLds& L, const uint4 c STAT_ARG) {
+    // (the brick is asked for before the roots are formed: its round trip overlaps the square root and the divisions — a candidate that
+    // cannot win has fetched it for nothing, a chain alone in its wave has one dependent round trip less per candidate)
+    const int e = (int)c.z;
+    const float4 blo = T.acc.brick[2 * e], bhi = T.acc.brick[2 * e + 1];
+    pool_candidate_b(T, s_nodes, L, c, blo, bhi STAT_PASS);
 }
 
 RT_DEV void pool_drain(const DevTree& T, const float4* s_nodes, WalkLds& L, int lane, unsigned& qn STAT_ARG) {
@@ -617,6 +621,37 @@ RT_DEV void walk_pool(const DevTree& T, const float4* s_nodes, WalkLds& L, const
             }
             // ---- phase 3: the tests
             unsigned qn = 0u;
+            if (RT_POOL_DIRECT && RT_POOL_SPANS == 1 && total <= 64u) {
+                // A round of at most one entry per lane (a thin wave's chains: the frame's critical path): the entry comes with its brick,
+                // and the lane that finds a candidate resolves it on the spot — no queue, and the brick's round trip rides on the entry's
+                // (a lone bounce: three dependent cache round trips in the walk become two).
+                PoolSpan& S = sp[0];
+                const bool act = S.cur < S.end;
+                STAT(st, ST_A_ITERS_WAVE, 1);
+                unsigned he = 0u;
+                if (act) {
+                    const uint2 sd = L.seg[S.sg];
+                    const unsigned p0 = L.pref[S.sg];
+                    he = sd.x - p0 + S.cur;
+                    S.owner = (int)(sd.y >> 26);
+                    const float4 r0 = L.ray[2 * S.owner], r1 = L.ray[2 * S.owner + 1];
+                    S.q.o = {r0.x, r0.y, r0.z}; S.q.d = {r0.w, r1.x, r1.y}; S.a = r1.z; S.abt = r1.w;
+                    S.atm = S.a * (0.001f * 0.9999f - 1e-6f);
+                }
+                const float4 s4 = hot[he], blo = A.brick[2 * he], bhi = A.brick[2 * he + 1];
+                STAT(st, ST_TESTS, act ? 1 : 0); STAT(st, ST_A_LANE_STEPS, act ? 1 : 0);
+                const float ocx = S.q.o.x - s4.x, ocy = S.q.o.y - s4.y, ocz = S.q.o.z - s4.z;
+                const float b = ocx * S.q.d.x + ocy * S.q.d.y + ocz * S.q.d.z;
+                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s4.w;
+                const float disc = b * b - S.a * c;
+                const float ab = fabsf(b);
+                const float Lm = __builtin_fmaf(ab, -1e-4f, -b) - S.abt, M = __builtin_fmaf(ab, -1e-4f, b) + S.atm;
+                const float P = fmaxf(Lm, M);
+                if (act && disc > 0.0f && !(P > 0.0f && P * P > disc * 1.0003f)) {
+                    STAT(st, ST_DISCPOS, 1);
+                    pool_candidate_b(T, s_nodes, L, make_uint4(__float_as_uint(b), __float_as_uint(disc), he, (unsigned)S.owner), blo, bhi STAT_PASS);
+                }
+            } else                                          // (pool_drain below, with nothing queued, is the fence before the owners pick up)
             while (true) {
                 bool any = false;
 #pragma unroll

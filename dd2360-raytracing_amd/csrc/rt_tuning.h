@@ -137,6 +137,9 @@
 #ifndef RT_POOL_SPANS
 #define RT_POOL_SPANS 1         // spans a lane steps through side by side in walk_pool (2, 4: within the +-1.5 % run-to-run noise)
 #endif
+#ifndef RT_POOL_DIRECT
+#define RT_POOL_DIRECT 1        // walk_pool: a round of at most 64 entries (one per lane) fetches each entry with its brick and resolves candidates where they are found
+#endif
 #ifndef RT_DENSE_PB
 #define RT_DENSE_PB 4           // entries per lane and pass of walk_pool_dense.  C5: 2: 850 ms, 3: 744, 4: 670, 5: 730, 8: 839
 #endif
