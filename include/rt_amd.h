@@ -167,15 +167,17 @@ int rt_octree_upload(rt_octree* octree);   /* the cudaMalloc + cudaMemcpy of mai
  * layout and plane table of the binary16 kernels, no candidate grid — again what rt_build_octree + rt_octree_upload give. */
 int rt_build_octree_gpu(const rt_world* world, int spheres_per_leaf, rt_octree** out, void* stream);
 /* one device-resident array of a tree, copied to the host (parity checks of the two builds; binary16 trees: 0-2 only): 0 traversal nodes, 1 bucket
- * entries (c, r^2), 2 entry -> sphere, 3/4 large spheres + bricks, 5 grid cell starts, 6/7 grid entries + bricks, 8/9 membership
+ * entries (c, r^2), 2 entry -> sphere, 3/4 large spheres + bricks, 5 strip bin starts (columns x fine bins; the x copy, then the z copy), 6/7 strip entries + bricks, 8/9 membership
  * lists, 10 cell -> node, 11/12 membership bitmaps.  *bytes = size of the array; copied when cap suffices. */
 int rt_octree_debug_array(const rt_octree* octree, int which, void* out, size_t cap, size_t* bytes);
 int rt_free_octree(rt_octree* octree);
 int rt_octree_flat_info(const rt_octree* octree, int* n_nodes, int* n_entries);   /* traversal copy: nodes used, bucket entries kept */
 /* How hitTree walks the tree on the device.  Both produce the reference's hit records bit for bit (fp32):
  * REFERENCE scans every bucket of every visited level-3 node like traverseTree (acceleration_structure.h:276-304);
- * FAST (default) tests only the spheres a conservative (x,z) grid says the ray can touch and falls back to the scan
- * for rays it cannot prove.  FP16 trees always use REFERENCE. */
+ * FAST (default) tests only the spheres a conservative (x,z) grid says the ray can touch — sorted strips: a sphere once
+ * per column it overlaps, keyed by the fine bin of its centre; grid_dim = columns per axis, cell_size = column width,
+ * grid_entries = registrations of the x copy — and falls back to the scan for rays it cannot prove (DESIGN.md 5.2,
+ * App. A).  FP16 trees always use REFERENCE. */
 int rt_octree_set_traversal(rt_octree* octree, int mode);
 int rt_octree_accel_info(const rt_octree* octree, int* grid_dim, float* cell_size, int* grid_entries, int* large_spheres);
 /* reference-layout view of the built tree (for parity checks): counts[0..leafCount), indices[leafCount*spl] */
