@@ -13,7 +13,8 @@ t0 = time.time()
 total_rays = 0
 list_worlds = 0
 N_WORLDS = int(sys.argv[1]) if len(sys.argv) > 1 else 24          # tools/campaign.py 240: ten times the default campaign
-for seed in range(N_WORLDS):
+FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 0               # tools/campaign.py 2400 2400: the next 2400 worlds
+for seed in range(FIRST, FIRST + N_WORLDS):
     n = [300, 1500, 6000, 20000][seed % 4]
     sp, cam = random_world(rt, 1000 + seed, n, 96, 64, big=3 + seed % 5, air=0.1 + 0.1 * (seed % 4))
     W = rt.World(n, 96, 64, spheres=sp, camera=cam); O = rt.Octree(W, 30 + 10 * (seed % 6))
