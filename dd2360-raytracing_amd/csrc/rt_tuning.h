@@ -10,7 +10,7 @@
 
 // ---- occupancy -----------------------------------------------------------------------------------------------------------------
 #ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 4       // waves per SIMD k_render is compiled for (512 / 4 = 128 VGPRs).  C3: 3: 22.5 ms, 4: 19.5, 5 (96 VGPRs, spills): 22.2
+#define RT_RENDER_WAVES 4       // waves per SIMD k_render is compiled for (512 / 4 = 128 VGPRs).  C3: 3: 22.5 ms, 4: 19.5, 5 (96 VGPRs, spills): 22.2; on round 4's kernels (116 VGPRs; 5: 68-80 B of scratch per lane, 5 120 waves resident): C3 14.0 -> 19.7 ms, C5 352 -> 437.  Fewer resident waves cost in proportion (7/8 of the grid: +8 %)
 #endif
 
 // ---- scheduling: long pixel chains ------------------------------------------------------------------------------
@@ -139,7 +139,7 @@
 #endif
 #ifndef RT_POOL_DIRECT
 #define RT_POOL_DIRECT 1        // walk_pool: a round of at most 64 entries (one per lane) fetches each entry with its brick and resolves candidates where they are found
-#endif
+#endif                          // (no queue; a lone bounce's walk has one dependent cache round trip less).  Kernel medians, interleaved runs: C2 0: 10.69 ms, 1: 10.38; C3 14.13 / 13.97; C5 flat
 #ifndef RT_DENSE_PB
 #define RT_DENSE_PB 4           // entries per lane and pass of walk_pool_dense.  C5: 2: 850 ms, 3: 744, 4: 670, 5: 730, 8: 839
 #endif
