@@ -13,12 +13,20 @@ enum { ST_RAYS, ST_FAST, ST_SLOW, ST_TIE, ST_COLS, ST_TESTS, ST_DISCPOS, ST_OFFE
        WP_B_OFFER, WP_B_CLIP, WP_COOP_CHUNK, WP_SCAN, WP_SC_ANY, WP_SC_LAMB, WP_SC_METAL, WP_SC_DIEL, WP_REJ_ITER, WP_PRIMARY, WP_DISK_ITER, WP_SKY, WP_ENDPIX,
        // cycles of the iterations of thin waves with <= 2 live lanes, by part (the critical path of the frame's tail)
        TH_GROUND, TH_LARGE_SETUP, TH_WALK, TH_SCAN, ST_N };
+#ifdef RT_STATS_LIGHT      // per-pixel and per-wave time stamps only (librt_amd_stats_light.so): the counters and cycle probes compile to nothing,
+#define TICK() 0ull        // the kernel runs within a few per cent of the product's — the timeline tools/stats.py prints is then the real one
+#else
 #define TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#endif
 __device__ unsigned long long g_stats[ST_N];
 __device__ int g_pilot_dbg[1 << 20];                  // per 2x2 block (tile * 16 + block): the pilot's bounce count
 __device__ unsigned long long g_wave_dbg[8192 * 4];   // per wave: end time (100 MHz ticks since launch), loop iters, thin iters, long pixels
 struct Stats { unsigned int c[ST_N]; unsigned long long cyc[8]; };
+#ifdef RT_STATS_LIGHT
+#define STAT(st, k, v) ((void)0)
+#else
 #define STAT(st, k, v) ((st).c[k] += (v))
+#endif
 #ifdef RT_STATS_WPASS      // (the atomics distort every timing of the same run: a build of its own, librt_amd_wpass.so)
 #define WPASS(k) do { const int l_ = (int)(threadIdx.x & 63); if (__builtin_amdgcn_readfirstlane(l_) == l_) atomicAdd(&g_stats[k], 1ull); } while (0)
 #else
