@@ -1047,6 +1047,14 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
     V3 q = {0.0f, 0.0f, 0.0f};
     WPASS(WP_SC_ANY);
     if (kind != RT_MAT_DIELECTRIC) q = random_in_unit_sphere(s);
+    // metal and dielectric both start from unit_vector(r_in.direction()) (material.h:69, :18): formed once for the lanes of either —
+    // a wave that holds both kinds (most do: 15 % metal, 5 % glass) walks through both branches, and paid the square root and the
+    // three divisions in each.  Same expression, same operands, same bits.
+    float len = 1.0f; V3 ud = {0.0f, 0.0f, 0.0f};
+    if (kind != RT_MAT_LAMBERTIAN) {
+        len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
+        ud.x = r.d.x / len; ud.y = r.d.y / len; ud.z = r.d.z / len;
+    }
     if (kind == RT_MAT_LAMBERTIAN) {                                                          // material.h:55-60
         WPASS(WP_SC_LAMB);
         const float tx = (p.x + n.x) + q.x, ty = (p.y + n.y) + q.y, tz = (p.z + n.z) + q.z;
@@ -1057,8 +1065,6 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
     }
     if (kind == RT_MAT_METAL) {                                                               // material.h:68-73
         WPASS(WP_SC_METAL);
-        const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
-        V3 ud; ud.x = r.d.x / len; ud.y = r.d.y / len; ud.z = r.d.z / len;
         const float k = 2.0f * dot3(ud, n);
         const float rx = ud.x - k * n.x, ry = ud.y - k * n.y, rz = ud.z - k * n.z;
         r.d.x = rx + m.w * q.x; r.d.y = ry + m.w * q.y; r.d.z = rz + m.w * q.z;
@@ -1072,7 +1078,6 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
     const float dn = dot3(r.d, n);
     const float k = 2.0f * dn;
     const float rx = r.d.x - k * n.x, ry = r.d.y - k * n.y, rz = r.d.z - k * n.z;            // reflect(dir, normal), dir not normalised
-    const float len = sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
     V3 on; float ni, cosine;
     if (dn > 0.0f) {
         on.x = -n.x; on.y = -n.y; on.z = -n.z; ni = ri;
@@ -1082,7 +1087,7 @@ RT_DEV bool scatter(const DevScene& S, int sphere, float t, RayF& r, V3& att, Rn
         on = n; ni = 1.0f / ri;
         cosine = -dn / len;
     }
-    V3 uv; uv.x = r.d.x / len; uv.y = r.d.y / len; uv.z = r.d.z / len;                        // refract(), material.h:17-31
+    const V3 uv = ud;                                                                         // refract(), material.h:17-31
     const float dt = dot3(uv, on);
     const float disc = 1.0f - ni * ni * (1.0f - dt * dt);
     float fx = 0.0f, fy = 0.0f, fz = 0.0f, reflect_prob;
