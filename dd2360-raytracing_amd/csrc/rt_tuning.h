@@ -39,6 +39,18 @@
 #ifndef RT_F_STATIC
 #define RT_F_STATIC 1.07f
 #endif
+// The sorted tail's pixels whose 3x3 pilot sum (18 one-sample paths; pure sky = 18) reaches RT_HEAD_SUM_* are handed out FIRST, before the
+// tiles, instead of last; 1 = the whole tail (blocks outside the frame count 0), 0 = none (the tail stays at the end of the queue).
+// Sparse grids, kernel ms, three runs each: C3 none 13.92-13.96, whole tail first 13.18-13.22 (the tail at 5 / 10 / 20 / 30 % of the work:
+// 13.65-13.98 / 13.34-13.58 / 13.47-13.80 / 14.8-15.1); C2 10.36-10.48 -> 9.28-9.46; only the non-sky pixels first (sum >= 19 / 20 / 22):
+// C3 13.84-14.25, C2 10.08-10.36.  Dense grids: the eight parts of C5 53.95 ms / 418.6 in all with none, 55.2 / 429.9 with the whole tail
+// first, 53.7-54.3 / 418-421 with sums 19-26; the whole frame does not see it.
+#ifndef RT_HEAD_SUM_SPARSE
+#define RT_HEAD_SUM_SPARSE 1
+#endif
+#ifndef RT_HEAD_SUM_DENSE
+#define RT_HEAD_SUM_DENSE 0
+#endif
 #ifndef RT_F_TAIL
 #define RT_F_TAIL 0.15f         // share of a launch's predicted work whose pixels are handed out one by one, most expensive 2x2 pilot block first, at the end of the
 #endif                          // queue (k_tail_hist / k_tail_scatter) instead of tile by tile; 0 = off
