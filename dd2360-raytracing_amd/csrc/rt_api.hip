@@ -741,7 +741,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     A.scene = world->z->dev;
     A.tree = tree_args(d_octree);
     A.order = nullptr; A.long_flag = nullptr; A.long_list = nullptr;
-    A.tail_list = nullptr; A.tail_ws = nullptr; A.f_tail = 0.f; A.head_sum = 0; A.head_sum_dense = 0;
+    A.tail_list = nullptr; A.tail_ws = nullptr; A.f_tail = 0.f; A.head_sum = 0; A.head_sum_dense = 0; A.head_min_load = 0.f;
     A.n_lanes = 0; A.f_inflight = tune_value("RT_F_INFLIGHT", RT_F_INFLIGHT); A.f_inflight_dense = tune_value("RT_F_INFLIGHT_DENSE", RT_F_INFLIGHT_DENSE); A.f_static = tune_value("RT_F_STATIC", RT_F_STATIC);
     const bool sched = mode == 0 && ns >= 4;
     // expensive tiles first (k_tile_cost / k_tile_order).  The workspace grows on first use of a larger frame: call rt_render
@@ -776,7 +776,7 @@ static int render_common(rt_render_ctx* ctx, void* fb, int max_x, int max_y, int
     }
     if (sched) {
         const bool classify = ns >= 16;          // long-chain pre-classification pays only when chains are long
-        if (classify && world->precision != RT_PRECISION_FP16) { A.tail_list = C.d_long + (size_t)A.n_local_tiles * 64; A.tail_ws = C.d_long + (size_t)C.sched_tiles * 128; A.f_tail = tune_value("RT_F_TAIL", RT_F_TAIL); A.head_sum = (int)tune_value("RT_HEAD_SUM_SPARSE", (float)RT_HEAD_SUM_SPARSE); A.head_sum_dense = (int)tune_value("RT_HEAD_SUM_DENSE", (float)RT_HEAD_SUM_DENSE); }
+        if (classify && world->precision != RT_PRECISION_FP16) { A.tail_list = C.d_long + (size_t)A.n_local_tiles * 64; A.tail_ws = C.d_long + (size_t)C.sched_tiles * 128; A.f_tail = tune_value("RT_F_TAIL", RT_F_TAIL); A.head_sum = (int)tune_value("RT_HEAD_SUM_SPARSE", (float)RT_HEAD_SUM_SPARSE); A.head_sum_dense = (int)tune_value("RT_HEAD_SUM_DENSE", (float)RT_HEAD_SUM_DENSE); A.head_min_load = tune_value("RT_HEAD_LOAD_DENSE", (float)RT_HEAD_LOAD_DENSE); }
         if (world->precision == RT_PRECISION_FP16) RT_TRY(launch_tile_order_h(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
         else RT_TRY(launch_tile_order(A, d_octree != nullptr, C.d_cost, C.d_order, classify ? C.d_flags : nullptr, classify ? C.d_long : nullptr, st));
         A.order = C.d_order;

@@ -145,7 +145,8 @@ struct RenderArgs {
     int32_t n_lanes;                      // lanes of the persistent render grid this launch will run on (64 x waves): the per-lane load is the yardstick of a "long" pixel
     const unsigned int* tail_list;        // the pixels of the last tiles of the hand-out order, most expensive 2x2 block first (k_tail_hist / k_tail_scatter); NULL = none
     unsigned int* tail_ws;                // 512 words behind the lists: the tail sort's 256 counts and 256 cursors
-    int32_t head_sum, head_sum_dense;     // tail pixels whose 3x3 pilot sum reaches this are handed out FIRST (0 = none; sparse grids / dense grids); queue[kQueueThr + 3] = how many, [kQueueThr + 4] = the sum in force
+    float head_min_load;                  // dense grids: launches of fewer predicted iterations per lane keep the whole tail at the end
+    int32_t head_sum, head_sum_dense;     // tail pixels whose 3x3 pilot sum reaches this — or, negative, is at most its magnitude — are handed out FIRST (0 = none; sparse grids / dense grids); queue[kQueueThr + 3] = how many, [kQueueThr + 4] = the sum in force, [kQueueThr + 5] = taken from the list's cheap end
     float f_tail;                         // share of the launch's predicted work handed out per pixel instead of per tile, at the end of the queue
     float f_inflight_dense;               // f_inflight of launches on dense grids (k_render<true,*,2>)
     float f_inflight, f_static;           // a pixel is long when its predicted chain exceeds f x (predicted iterations of the launch / n_lanes): found in flight / by the pilot

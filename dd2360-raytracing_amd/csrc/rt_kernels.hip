@@ -1226,7 +1226,11 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(RenderArgs A) {
             const long long tail0 = (MODE == 0 && A.tail_list) ? (long long)A.queue[kQueueThr + 2] : 0;
             const long long head = tail0 > 0 ? (long long)A.queue[kQueueThr + 3] : 0;
             if (tail0 > 0 && (slot < head || slot >= tail0 - 1 + head)) {
-                const unsigned int pid = A.tail_list[slot < head ? slot : slot - (tail0 - 1)];
+                // (head taken from the list's cheap END — queue[kQueueThr + 5] — : the sky first, the rest of the list, most expensive first, last)
+                const bool from_end = A.queue[kQueueThr + 5] != 0u;
+                const long long n_tail = n_slots - (tail0 - 1);
+                const long long k = slot < head ? (from_end ? n_tail - head + slot : slot) : (from_end ? slot - (tail0 - 1) - head : slot - (tail0 - 1));
+                const unsigned int pid = A.tail_list[k];
                 local_tile = (long long)(pid >> 6); l = (int)(pid & 63u);
             } else {
                 constexpr int kIl = COOPG == 2 ? RT_INTERLEAVE_DENSE : (COOPG == 5 ? RT_INTERLEAVE_SOLO : RT_INTERLEAVE);   // tiles whose pixels interleave (consecutive slots: one pixel position of kIl tiles)
@@ -1597,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_long_select(RenderArgs A, const unsigne
 // unless it runs in a thin wave from early on; whether 3000 bounces are long depends on the launch (C5 whole frame: load 18 000;
 // one part of eight: 2 250).  queue[kQueueThr] = in-flight threshold in iterations, queue[kQueueThr + 1] = the same as a 3x3 pilot sum (18 samples).
 __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, unsigned int* __restrict__ order, long long n, unsigned int* __restrict__ queue,
-                                                    int ns, int n_lanes, float f_inflight, float f_static, float f_tail, long long tail_cap_tiles, unsigned int* __restrict__ tail_ws, int head_sum) {
+                                                    int ns, int n_lanes, float f_inflight, float f_static, float f_tail, long long tail_cap_tiles, unsigned int* __restrict__ tail_ws, int head_sum, float head_min_load) {
     if (tail_ws && threadIdx.x < 512) tail_ws[threadIdx.x] = 0u;   // (the tail sort's counts and cursors: k_tail_hist / k_tail_scatter run after this kernel)
     __shared__ int s_cnt[16][8];
     __shared__ long long s_sum[16];
@@ -1663,7 +1667,11 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
         }
         queue[kQueueThr + 2] = tail_mark;
         // the tail's pixels whose 3x3 pilot sum reaches head_sum are handed out before the tiles (k_tail_scatter counts them; 0 = none)
-        queue[kQueueThr + 4] = (tail_mark != 0u && head_sum > 0) ? (unsigned int)(head_sum > 255 ? 255 : head_sum) : 0u;
+        // (head_sum < 0: the pixels whose sum is AT MOST -head_sum — the list's cheap end, the sky — are handed out first instead;
+        // launches below head_min_load iterations per lane keep the whole list at the end: they need their cheapest pixels for the drain)
+        if (load < (double)head_min_load) head_sum = 0;
+        queue[kQueueThr + 4] = (tail_mark != 0u && head_sum > 0) ? (unsigned int)(head_sum > 255 ? 255 : head_sum) : (tail_mark != 0u && head_sum < 0) ? (unsigned int)(-head_sum >= 254 ? 255 : -head_sum + 1) : 0u;
+        queue[kQueueThr + 5] = (tail_mark != 0u && head_sum < 0) ? 1u : 0u;
         queue[kQueueThr] = f_inflight > 0.f ? (unsigned int)(ti < 1.0 ? 1.0 : (ti > 4.0e9 ? 4.0e9 : ti)) : 0u;
         queue[kQueueThr + 1] = f_static > 0.f ? (unsigned int)(tsum < 1.0 ? 1.0 : (tsum > 1.0e9 ? 1.0e9 : tsum)) : 0u;
     }
@@ -1764,8 +1772,9 @@ __global__ __launch_bounds__(256) void k_tail_scatter(const unsigned int* __rest
     for (int w = 0; w < wave; ++w) start += s_wave[w];
     // the list's first entries — every pixel whose 3x3 sum reaches the head threshold (values 255 ... thr = bins 0 ... 255 - thr) — are
     // handed out before the tiles: their count is where bin 256 - thr begins
+    // (from the cheap end, queue[kQueueThr + 5]: every entry whose sum is below thr — what follows the entries counted above)
     { const unsigned int thr = queue[kQueueThr + 4];
-      if (blockIdx.x == 0 && thr != 0u && threadIdx.x == 256u - thr) queue[kQueueThr + 3] = start; }
+      if (blockIdx.x == 0 && thr != 0u && threadIdx.x == 256u - thr) queue[kQueueThr + 3] = queue[kQueueThr + 5] != 0u ? (unsigned int)(n_blocks * 4) - start : start; }
     unsigned int local[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) local[u] = key[u] >= 0 ? atomicAdd(&s_bin[key[u]], 4u) : 0u;
@@ -1957,7 +1966,7 @@ hipError_t launch_select_and_order(const RenderArgs& A, int* cost, unsigned int*
     // flags: 64 bytes per local tile (one per pixel), 16 (the pilot's count per 2x2 block), 16 (that count summed over the block's 3x3 neighbourhood)
     const bool tail = flags && A.tail_list && A.tail_ws && A.f_tail > 0.f;
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const int*)cost, order, (long long)A.n_local_tiles, A.queue, (int)A.ns, (int)A.n_lanes, A.f_inflight, A.f_static,
-                       tail ? A.f_tail : 0.f, (long long)A.n_local_tiles, tail ? A.tail_ws : (unsigned int*)nullptr, tail ? A.head_sum : 0);
+                       tail ? A.f_tail : 0.f, (long long)A.n_local_tiles, tail ? A.tail_ws : (unsigned int*)nullptr, tail ? A.head_sum : 0, A.head_min_load);
     if (flags) {
         const unsigned char* pilot = flags + (size_t)A.n_local_tiles * 64;
         unsigned char* sum8 = flags + (size_t)A.n_local_tiles * 80;
@@ -1996,6 +2005,7 @@ hipError_t launch_tile_order(const RenderArgs& A, bool tree, int* cost, unsigned
     B.n_lanes = tree ? (int)render_grid_blocks(A, variant, 0) * 256 : 0;      // (list scans keep the rate rule alone)
     if (variant == 2 && A.f_inflight_dense > 0.f) B.f_inflight = A.f_inflight_dense;
     B.head_sum = variant == 2 ? A.head_sum_dense : A.head_sum;
+    B.head_min_load = variant == 2 ? A.head_min_load : 0.f;
     { const hipError_t e = launch_pilot(A, tree, cost, pilot, nullptr, st); if (e != hipSuccess) return e; }
     // (chains in waves of their own: the variant for very sparse grids)
     return launch_select_and_order(B, cost, order, flags, long_list, st, 0, variant == 5 ? RT_PILOT_SOLO_SUM : 0x7fffffff);

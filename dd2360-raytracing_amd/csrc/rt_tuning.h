@@ -43,13 +43,23 @@
 // tiles, instead of last; 1 = the whole tail (blocks outside the frame count 0), 0 = none (the tail stays at the end of the queue).
 // Sparse grids, kernel ms, three runs each: C3 none 13.92-13.96, whole tail first 13.18-13.22 (the tail at 5 / 10 / 20 / 30 % of the work:
 // 13.65-13.98 / 13.34-13.58 / 13.47-13.80 / 14.8-15.1); C2 10.36-10.48 -> 9.28-9.46; only the non-sky pixels first (sum >= 19 / 20 / 22):
-// C3 13.84-14.25, C2 10.08-10.36.  Dense grids: the eight parts of C5 53.95 ms / 418.6 in all with none, 55.2 / 429.9 with the whole tail
-// first, 53.7-54.3 / 418-421 with sums 19-26; the whole frame does not see it.
+// C3 13.84-14.25, C2 10.08-10.36.
+// A negative value takes the head from the list's cheap END: the pixels whose sum is at most its magnitude (the sky) first, the rest of
+// the list, most expensive first, last.  Why first helps: a wave's bounce is as long as its slowest lane's, and sky pixels handed out
+// one by one at the end of the queue ride in waves that still walk the grid (13.0 us an iteration); first, they fill waves of their
+// own (9.1 us) and the queue is empty 1.3 ms earlier (C3: profiles/r4/timeline_c3_real_pace.txt and timeline_c3_tail_first.txt).
+// Dense grids, kernel ms: the whole C5 frame none 352.8-354.1, whole tail first 341.7-344.4, sky first (-18 / -19) 342.8-344.1; halves
+// 185.2 -> 179.2; quarters 96.0-97.2 none, 96.5 whole tail, 95.2-95.6 sky (-21 / -19); eighths 54.0-54.2 none, 55.2 whole tail, 54.6-56.6
+// sky: a launch of few pixels per lane needs its cheapest pixels for the drain — below RT_HEAD_LOAD_DENSE predicted iterations per
+// lane (whole 18 000, half 9 000, quarter 4 500, eighth 2 250) the tail stays where it was.
 #ifndef RT_HEAD_SUM_SPARSE
 #define RT_HEAD_SUM_SPARSE 1
 #endif
 #ifndef RT_HEAD_SUM_DENSE
-#define RT_HEAD_SUM_DENSE 0
+#define RT_HEAD_SUM_DENSE -21
+#endif
+#ifndef RT_HEAD_LOAD_DENSE
+#define RT_HEAD_LOAD_DENSE 3500
 #endif
 #ifndef RT_F_TAIL
 #define RT_F_TAIL 0.15f         // share of a launch's predicted work whose pixels are handed out one by one, most expensive 2x2 pilot block first, at the end of the
