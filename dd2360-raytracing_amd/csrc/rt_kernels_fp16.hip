@@ -749,16 +749,22 @@ RT_DEV bool scatter(const DevScene& S, int sphere, R t, Ray& r, V& att, Rng& s) 
     const V p = vadd(r.o, vscale(t, r.d));                                  // ray.h:13
     const V n = vdiv(vsub(p, c), rf(g.w));                                  // sphere.h:29
     const V albedo = {rf(m.x), rf(m.y), rf(m.z)};
+    // As in the float kernel: lambertian and metal both draw exactly one random_in_unit_sphere and nothing else — one shared rejection
+    // loop instead of one per branch; metal and dielectric both start from unit_vector(r_in.direction()) — formed once.  A wave holds
+    // all three kinds and walks through every branch; the draws keep their order, the expressions their operands.
+    V q = {ri(0), ri(0), ri(0)};
+    if (kind != RT_MAT_DIELECTRIC) q = random_in_unit_sphere(s);
+    V ud = {ri(0), ri(0), ri(0)};
+    if (kind != RT_MAT_LAMBERTIAN) ud = vunit(r.d);
     if (kind == RT_MAT_LAMBERTIAN) {
-        const V target = vadd(vadd(p, n), random_in_unit_sphere(s));
+        const V target = vadd(vadd(p, n), q);
         r.d = vsub(target, p); r.o = p;
         att = vmul(att, albedo);
         return true;
     }
     if (kind == RT_MAT_METAL) {
-        const V ud = vunit(r.d);
         const V refl = vsub(ud, vscale(rf(2.0f) * vdot(ud, n), n));
-        r.d = vadd(refl, vscale(rf(m.w), random_in_unit_sphere(s)));
+        r.d = vadd(refl, vscale(rf(m.w), q));
         r.o = p;
         att = vmul(att, albedo);
         return vdot(r.d, n) > rf(0.0f);
@@ -776,7 +782,7 @@ RT_DEV bool scatter(const DevScene& S, int sphere, R t, Ray& r, V& att, Rng& s) 
         cosine = rf(-fl(vdot(r.d, n)) / fl(vlen(r.d)));                     // float negate, float divide, one rounding
     }
     // refract (material.h:17-31)
-    const V uv = vunit(r.d);
+    const V uv = ud;
     const R dt = vdot(uv, outward);
     const R disc = rf(1.0f) - ni_over_nt * ni_over_nt * (rf(1.0f) - dt * dt);
     V refracted = {ri(0), ri(0), ri(0)};
